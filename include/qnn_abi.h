@@ -1,0 +1,169 @@
+/*
+ * qnn_abi.h -- C ABI of the MI355X (gfx950) low-bit forward engine.
+ *
+ * This is the drop-in boundary for the reference's low-bit forward path.  The
+ * reference (victorjoos/QuantizedNeuralNetworks-Keras-Tensorflow) has no FFI of
+ * its own: the path sits behind the Keras Layer API and runs as a TensorFlow
+ * sub-graph.  Each entry point below replaces the TF ops one reference function
+ * emits (file:line cited per function); the Python host classes in
+ * quantizedneuralnetworks-keras-tensorflow_amd/layers/ keep the Keras surface
+ * and bind these symbols through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *   - every function returns 0 (QNN_OK) or a negative QNN_E* code;
+ *     qnn_last_error() returns a thread-local human-readable message.
+ *   - the CALLER owns every device buffer passed in; the library allocates
+ *     device memory only inside an opaque prepacked-weights handle.
+ *   - all work is enqueued on the caller's stream (a hipStream_t passed as
+ *     void*; NULL = default stream); nothing synchronises the device.
+ *   - tensors are NHWC, kernels HWIO, dense kernels (in, units): Keras layouts.
+ *   - functions are re-entrant for distinct streams / handles.
+ *
+ * Packed activation storage (NHWC, channel-fastest, little-endian words):
+ *   QNN_STORE_BIN  1 bit / channel, 32 channels per uint32, bit j of word w is
+ *                  channel 32*w+j, bit = 1 <=> +1, bit = 0 <=> -1; channels are
+ *                  padded with 0 bits up to a multiple of 32.
+ *   QNN_STORE_I4   signed 4-bit two's-complement codes, 8 per uint32, nibble j
+ *                  of word w is channel 8*w+j; value = code / 2^(abits-1);
+ *                  2- and 3-bit activations are stored sign-extended in 4 bits.
+ *   QNN_STORE_I8   signed 8-bit codes, 4 per uint32.
+ *   Words per pixel = ceil(C / (32 / bits)).
+ */
+#ifndef QNN_ABI_H
+#define QNN_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QNN_ABI_VERSION 1
+
+/* status codes */
+#define QNN_OK            0
+#define QNN_EINVAL       -1   /* bad argument (shape, kind, null pointer) */
+#define QNN_EUNSUPPORTED -2   /* valid request this build has no kernel for */
+#define QNN_EHIP         -3   /* a HIP runtime call failed */
+#define QNN_ENOMEM       -4
+
+/* storage kinds of activation / weight tensors */
+#define QNN_STORE_F32 0
+#define QNN_STORE_BIN 1
+#define QNN_STORE_I4  4
+#define QNN_STORE_I8  8
+
+/* weight quantizers (what the layer applies to its latent fp32 kernel) */
+#define QNN_W_FLOAT    0   /* stock Conv2D / Dense: kernel used as is          */
+#define QNN_W_BINARY   1   /* binarize(W, H)      layers/binary_ops.py:54-64   */
+#define QNN_W_QUANT    2   /* quantize(W, nb)     layers/quantized_ops.py:49-66 */
+#define QNN_W_TERNARY  3   /* ternarize(W, H)     layers/ternary_ops.py:33-41  */
+
+/* activation functions (layers/ *_ops.py) */
+#define QNN_FN_NONE            0
+#define QNN_FN_BINARY_TANH     1   /* binary_ops.py:37-51                       */
+#define QNN_FN_QUANTIZED_TANH  2   /* quantized_ops.py:87-100 (= quantize_op)    */
+#define QNN_FN_TERNARY_TANH    3   /* ternary_ops.py:52-54                      */
+#define QNN_FN_GRID            4   /* input is already on the grid: encode only  */
+
+typedef struct qnn_weights qnn_weights_t;   /* opaque prepacked layer weights */
+
+/*
+ * Epilogue fused behind the contraction.  Steps, in the reference's op order:
+ *   v = acc * 2^-(wshift+xshift)             conv / matmul result (exact)
+ *   v = v + bias[c]                           K.bias_add   (if the layer has bias)
+ *   v = v*bn_inv[c] + bn_shift[c]             inference BatchNormalization, two
+ *                                             roundings (vgg.py:16, resnet.py:61)
+ *   v = fn(v)                                 binary_tanh / quantized_tanh(act_bits)
+ *   v = max over a pool x pool window         MaxPooling2D(2,2) (vgg.py:23,30,37)
+ *   store as out_store (F32 value, or packed code)
+ * bn_inv / bn_shift are device pointers to per-channel float32 constants formed
+ * by the host exactly as tf.nn.batch_normalization forms them; NULL = no BN.
+ */
+typedef struct qnn_epilogue {
+    const float* bn_inv;     /* [cout] or NULL                                  */
+    const float* bn_shift;   /* [cout] or NULL                                  */
+    int32_t fn;              /* QNN_FN_NONE | _BINARY_TANH | _QUANTIZED_TANH     */
+    int32_t act_bits;        /* nb of quantized_tanh (ignored otherwise)         */
+    int32_t pool;            /* 1 = none, 2 = 2x2 max pool stride 2 'valid'      */
+    int32_t out_store;       /* QNN_STORE_F32 | _BIN | _I4 | _I8                 */
+} qnn_epilogue_t;
+
+/* ---- library ------------------------------------------------------------ */
+int         qnn_version(void);
+const char* qnn_last_error(void);
+
+/* ---- elementwise activation clips on float32 tensors --------------------- */
+/* binary_ops.binary_tanh, layers/binary_ops.py:37-51 */
+int qnn_binary_tanh_f32(const float* x, float* y, size_t n, void* stream);
+/* quantized_ops.quantized_tanh (and quantize), layers/quantized_ops.py:49-66,87-100 */
+int qnn_quantized_tanh_f32(const float* x, float* y, size_t n, int nb, void* stream);
+/* ternary_ops.ternary_tanh, layers/ternary_ops.py:52-54.  Needs the global
+ * mean(|clip(x)|) first: workspace = 2 doubles... provided by caller (16 bytes,
+ * device memory).  Two kernels on `stream`. */
+int qnn_ternary_tanh_f32(const float* x, float* y, size_t n, void* workspace16, void* stream);
+
+/* ---- pack / unpack between float32 NHWC and packed storage --------------- */
+/* bytes of a packed tensor of `pixels` pixels x `channels` channels */
+size_t qnn_packed_bytes(int store, size_t pixels, int channels);
+/* y = encode(fn(x)):  fn = QNN_FN_BINARY_TANH -> BIN; QNN_FN_QUANTIZED_TANH(nb)
+ * -> I4/I8 codes; QNN_FN_GRID -> x is already +-1 (BIN: bit = x > 0) or k/2^(nb-1). */
+int qnn_pack_f32(const float* x, void* y, size_t pixels, int channels,
+                 int fn, int nb, int store, void* stream);
+/* inverse of the encoding: float32 value of every stored code */
+int qnn_unpack_f32(const void* x, float* y, size_t pixels, int channels,
+                   int store, int nb, void* stream);
+
+/* ---- weights -------------------------------------------------------------- */
+/*
+ * Quantize + pack a layer's latent float32 kernel once (the reference re-runs
+ * binarize/quantize every Session.run: binary_layers.py:161, quantized_layers.py:165).
+ *   wkind/wbits : QNN_W_* and nb of quantize()
+ *   H           : the layers' H (binarize(W,H)); 1.0 in every model
+ *   kernel      : DEVICE pointer, float32 HWIO (kh,kw,cin,cout); dense: kh=kw=1
+ *   bias        : DEVICE pointer [cout] or NULL (use_bias=False)
+ *   stride      : 1 or 2 (square); same_pad: 1 = 'same', 0 = 'valid'
+ *   store       : packed kind to prepare for the integer path (QNN_STORE_BIN only
+ *                 for QNN_W_BINARY; I4 needs wbits<=4; I8 needs wbits<=8), or
+ *                 QNN_STORE_F32 for "float32 inputs only" (first layer).
+ */
+int qnn_prepack_weights(int wkind, int wbits, float H, const float* kernel,
+                        int kh, int kw, int cin, int cout, const float* bias,
+                        int stride, int same_pad, int store, void* stream,
+                        qnn_weights_t** out);
+int qnn_free_weights(qnn_weights_t* w);
+/* read back the quantized kernel as float32 HWIO into a DEVICE buffer (tests) */
+int qnn_weights_dequant(const qnn_weights_t* w, float* kernel_hwio, void* stream);
+
+/* ---- the contractions ------------------------------------------------------ */
+/*
+ * BinaryConv2D.call  (layers/binary_layers.py:160-187) and
+ * QuantizedConv2D.call (layers/quantized_layers.py:164-194), with the
+ * lr-multiplier identity trick treated as the identity ("exact" mode).
+ *   x        : DEVICE, NHWC; x_store = QNN_STORE_F32 (any float32 values: the
+ *              first layer, or the generic fallback) or a packed kind
+ *   x_bits   : abits of the packed codes (value = code/2^(x_bits-1); BIN: 1)
+ *   y        : DEVICE, NHWC (N, Ho/pool, Wo/pool, cout) float32 or packed
+ * Output geometry: Ho = ceil(H/stride) for 'same'.
+ */
+int qnn_conv2d_forward(const qnn_weights_t* w, const void* x, int x_store, int x_bits,
+                       int N, int H, int W, const qnn_epilogue_t* epi, void* y,
+                       void* stream);
+/*
+ * BinaryDense.call (layers/binary_layers.py:78-85) / QuantizedDense.call
+ * (layers/quantized_layers.py:79-88): x (N, in) float32 or packed -> y (N, units).
+ * pool must be 1.
+ */
+int qnn_dense_forward(const qnn_weights_t* w, const void* x, int x_store, int x_bits,
+                      int N, const qnn_epilogue_t* epi, void* y, void* stream);
+
+/* Name of the kernel variant the last qnn_conv2d_forward / qnn_dense_forward on
+ * this thread dispatched to ("ps_bin_cw2_k3", "generic", "mfma_i8", ...). */
+const char* qnn_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QNN_ABI_H */

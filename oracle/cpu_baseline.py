@@ -1,0 +1,118 @@
+"""CPU baseline for bench.py -- TEST/BENCH INFRASTRUCTURE, NOT PRODUCT.
+
+"Restated reference float path (not TensorFlow)": TensorFlow/Keras are absent from
+this image and from the GPU box, so the reference's own CPU path cannot be timed.
+This module replays, on PyTorch-CPU with every host core, exactly the op sequence
+the reference's graph executes per Session.run (TF-op table):
+weights fake-quantized every forward (binary_layers.py:161 / quantized_layers.py:165),
+the lr-multiplier identity trick as three elementwise passes on the input and three
+on the output (binary_layers.py:163-165,175-176), a float32 NHWC conv / matmul,
+bias add, inference BN as mul+add, the activation clip as its chain of elementwise
+ops, and max-pooling.  kind = "port".
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import qnn_oracle as O
+
+
+def _round_through(x):
+    return x + (torch.round(x) - x)          # torch.round is half-to-even
+
+
+def _binary_tanh(x):
+    h = torch.clamp(0.5 * x + 0.5, 0.0, 1.0)
+    return 2.0 * _round_through(h) - 1.0
+
+
+def _quantize(x, nb):
+    m = float(2 ** (nb - 1))
+    return torch.clamp(_round_through(x * m), -m, m - 1) / m
+
+
+def _trick(x, c, s):
+    return (x - c * x) * s
+
+
+def forward(spec, x):
+    """x: float32 NHWC torch CPU tensor (sequential specs only)."""
+    cur = x
+    for op in spec:
+        k = op["op"]
+        if k == "conv":
+            w = op["_w"]
+            wq = _binary_tanh(w) if op["kind"] == "binary" else _quantize(w, op["nb"])
+            c_in, s_in, c_out, s_out = op["_trick"]
+            xin = _trick(cur, c_in, s_in)
+            y = F.conv2d(xin.permute(0, 3, 1, 2), wq.permute(3, 2, 0, 1), None,
+                         stride=op.get("strides", (1, 1)), padding=1 if w.shape[0] == 3 else 0)
+            y = _trick(y.permute(0, 2, 3, 1), c_out, s_out)
+            cur = y + op["_b"] if op.get("bias") is not None else y
+        elif k == "dense":
+            w = op["_w"]
+            wq = _binary_tanh(w) if op["kind"] == "binary" else _quantize(w, op["nb"])
+            cur = cur @ wq
+            if op.get("bias") is not None:
+                cur = cur + op["_b"]
+        elif k == "bn":
+            cur = cur * op["_inv"] + op["_shift"]
+        elif k == "act":
+            cur = _binary_tanh(cur) if op["fn"] == "binary_tanh" else _quantize(cur, op["nb"])
+        elif k == "maxpool":
+            cur = F.max_pool2d(cur.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        elif k == "flatten":
+            cur = cur.reshape(cur.shape[0], -1)
+        else:
+            raise ValueError(k)
+    return cur
+
+
+def prepare(spec):
+    out = []
+    for op in spec:
+        op = dict(op)
+        if op["op"] in ("conv", "dense"):
+            op["_w"] = torch.as_tensor(op["kernel"])
+            if op.get("bias") is not None:
+                op["_b"] = torch.as_tensor(op["bias"])
+            if op["op"] == "conv":
+                kh, kw, ci, co = op["kernel"].shape
+                op["_trick"] = tuple(float(v) for v in O.trick_constants(O.glorot_klm(kh, kw, ci, co)))
+        elif op["op"] == "bn":
+            inv, shift = O.bn_constants(op["gamma"], op["beta"], op["mean"], op["var"], op["eps"])
+            op["_inv"], op["_shift"] = torch.as_tensor(inv), torch.as_tensor(shift)
+        out.append(op)
+    return out
+
+
+def run(cf, spec, seconds=12.0, batch=256):
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    prepared = prepare(spec)
+    rng = np.random.default_rng(1)
+    x = torch.as_tensor((rng.integers(0, 256, (batch, cf.dim, cf.dim, cf.channels)).astype(np.float32)
+                         / np.float32(255)))
+    with torch.no_grad():
+        forward(prepared, x)                      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            forward(prepared, x)
+            n += batch
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                break
+    cpu = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d images (batches of %d) of the same workload in %.1f s; restated reference "
+                      "float path (not TensorFlow) on PyTorch-CPU, %s" % (n, batch, dt, cpu)}

@@ -180,6 +180,67 @@ def conv2d(x, w, strides=(1, 1), padding="same"):
     return out.astype(np.float32)
 
 
+def fma32(a, b, c):
+    """Correctly rounded float32 fused multiply-add a*b+c (what v_fma_f32 computes),
+    emulated in float64: the product of two float32 is exact in float64, TwoSum gives
+    the exact error of the float64 addition, and the final rounding to float32 is
+    repaired when the float64 sum sits exactly on a float32 tie."""
+    a64 = np.asarray(a, dtype=np.float32).astype(np.float64)
+    b64 = np.asarray(b, dtype=np.float32).astype(np.float64)
+    c64 = np.asarray(c, dtype=np.float32).astype(np.float64)
+    p = a64 * b64
+    s = p + c64
+    bb = s - p
+    e = (p - (s - bb)) + (c64 - bb)            # s + e == p + c exactly
+    r = s.astype(np.float32)
+    t = r.astype(np.float64)
+    d = s - t                                  # exact
+    toward = np.where(d > 0, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32)
+    nb = np.nextafter(r, toward)
+    half = (nb.astype(np.float64) - t) * 0.5
+    tie = (d != 0) & (d == half)
+    fix = tie & (e != 0) & (np.sign(e) == np.sign(d))
+    return np.where(fix, nb, r).astype(np.float32)
+
+
+def conv2d_device_order(x, w, strides=(1, 1), padding="same"):
+    """Float32 conv in the accumulation order of the HIP kernels: acc = 0, then one
+    float32 FMA per (dy, dx, ci) in that order (out-of-image taps contribute
+    fma(0, w, acc) = acc).  This is one valid instance of the unspecified summation
+    order of tf.nn.convolution; it lets float-input layers be compared bit-for-bit."""
+    x = _f32(x)
+    w = _f32(w)
+    N, H, W_, C = x.shape
+    kh, kw, ci, co = w.shape
+    sh, sw = strides
+    if padding == "same":
+        Ho, pt, pb = same_padding(H, kh, sh)
+        Wo, pl, pr = same_padding(W_, kw, sw)
+    else:
+        Ho = (H - kh) // sh + 1
+        Wo = (W_ - kw) // sw + 1
+        pt = pb = pl = pr = 0
+    xp = np.zeros((N, H + pt + pb, W_ + pl + pr, C), dtype=np.float32)
+    xp[:, pt:pt + H, pl:pl + W_, :] = x
+    acc = np.zeros((N, Ho, Wo, co), dtype=np.float32)
+    for dy in range(kh):
+        for dx in range(kw):
+            patch = xp[:, dy:dy + (Ho - 1) * sh + 1:sh, dx:dx + (Wo - 1) * sw + 1:sw, :]
+            for c in range(C):
+                acc = fma32(patch[..., c:c + 1], w[dy, dx, c][None, None, None, :], acc)
+    return acc
+
+
+def _on_grid(x):
+    """True if every value is a multiple of 2**-7 in [-1, 1] (any <=8-bit activation
+    grid, or +-1): sums of such values times <=8-bit weights are exact in any order."""
+    x = np.asarray(x, dtype=np.float32)
+    if x.size == 0:
+        return True
+    k = x.astype(np.float64) * 128.0
+    return bool(np.abs(x).max() <= 1.0 and np.array_equal(k, np.rint(k)))
+
+
 def dot(x, w):
     """K.dot -> tf.matmul, (N,K)x(K,units); float64 accumulate, one rounding."""
     return _f32(x).astype(np.float64).dot(_f32(w).astype(np.float64)).astype(np.float32)
@@ -291,9 +352,18 @@ def _trick(x, c, s):
 # --------------------------------------------------------------------------
 # layers/binary_layers.py and layers/quantized_layers.py :: call()
 # --------------------------------------------------------------------------
+FLOAT_CONV = {"order": "ideal"}   # "ideal" (float64 accumulate) | "device" (FMA chain)
+
+
+def _conv(x, qkernel, strides, padding):
+    if FLOAT_CONV["order"] == "device" and not _on_grid(x):
+        return conv2d_device_order(x, qkernel, strides, padding)
+    return conv2d(x, qkernel, strides, padding)
+
+
 def _conv_call(x, qkernel, bias, klm, strides, padding, mode, promotion):
     if mode == "exact":
-        out = conv2d(x, qkernel, strides, padding)
+        out = _conv(x, qkernel, strides, padding)
     elif mode == "faithful":
         c_in, s_in, c_out, s_out = trick_constants(klm, promotion)
         xin = _trick(x, c_in, s_in)
@@ -338,7 +408,7 @@ def quantized_dense_call(x, kernel, bias=None, nb=16):
 
 def float_conv2d_call(x, kernel, bias=None, strides=(1, 1), padding="same"):
     """Stock keras Conv2D (network_type 'float', model_factory.py:24-26)."""
-    out = conv2d(x, kernel, strides, padding)
+    out = _conv(x, kernel, strides, padding)
     return bias_add(out, bias) if bias is not None else out
 
 
@@ -390,10 +460,19 @@ def signs_of(xb):
 # Topologies follow models/vgg.py:5-44 and models/resnet.py:26-144; the spec is
 # produced by the product's nets.py builder (plain numpy data, no code shared).
 # --------------------------------------------------------------------------
-def run_spec(spec, x, mode="exact", promotion="legacy", return_all=False):
+def run_spec(spec, x, mode="exact", promotion="legacy", return_all=False, float_conv="ideal"):
     """Interpret ``spec`` on NHWC float32 input ``x``.  Each op dict may name
     ``src`` (default: previous output) and ``dst``.  Returns the last tensor (or
-    the dict of all named tensors)."""
+    the dict of all named tensors).  ``float_conv="device"`` evaluates convolutions
+    of non-grid inputs (the raw image) in the HIP kernels' FMA order."""
+    FLOAT_CONV["order"] = float_conv
+    try:
+        return _run_spec(spec, x, mode, promotion, return_all)
+    finally:
+        FLOAT_CONV["order"] = "ideal"
+
+
+def _run_spec(spec, x, mode, promotion, return_all):
     env = {"input": _f32(x)}
     cur = env["input"]
     for i, op in enumerate(spec):

@@ -1,0 +1,217 @@
+"""ctypes binding of include/qnn_abi.h (csrc/libqnn_hip.so).
+
+The library is loaded eagerly and loudly: a missing or unloadable .so raises at
+import time of any op that needs it (there is no CPU implementation to fall back
+to).  Tensors cross the boundary as raw device pointers (``tensor.data_ptr()``)
+plus the current HIP stream of torch.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _build
+
+QNN_OK = 0
+STORE_F32, STORE_BIN, STORE_I4, STORE_I8 = 0, 1, 4, 8
+W_FLOAT, W_BINARY, W_QUANT, W_TERNARY = 0, 1, 2, 3
+FN_NONE, FN_BINARY_TANH, FN_QUANTIZED_TANH, FN_TERNARY_TANH, FN_GRID = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "qnn_version", "qnn_last_error", "qnn_last_kernel",
+    "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
+    "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32",
+    "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant",
+    "qnn_conv2d_forward", "qnn_dense_forward",
+]
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [("bn_inv", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
+                ("fn", ctypes.c_int32), ("act_bits", ctypes.c_int32),
+                ("pool", ctypes.c_int32), ("out_store", ctypes.c_int32)]
+
+
+class QnnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Return the loaded library; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise QnnError(
+            "libqnn_hip.so is not built (%s). Run `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` (needs hipcc). There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    vp, ci, sz, fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
+    lib.qnn_version.restype = ci
+    lib.qnn_last_error.restype = ctypes.c_char_p
+    lib.qnn_last_kernel.restype = ctypes.c_char_p
+    lib.qnn_binary_tanh_f32.argtypes = [vp, vp, sz, vp]
+    lib.qnn_quantized_tanh_f32.argtypes = [vp, vp, sz, ci, vp]
+    lib.qnn_ternary_tanh_f32.argtypes = [vp, vp, sz, vp, vp]
+    lib.qnn_packed_bytes.argtypes = [ci, sz, ci]
+    lib.qnn_packed_bytes.restype = sz
+    lib.qnn_pack_f32.argtypes = [vp, vp, sz, ci, ci, ci, ci, vp]
+    lib.qnn_unpack_f32.argtypes = [vp, vp, sz, ci, ci, ci, vp]
+    lib.qnn_prepack_weights.argtypes = [ci, ci, fl, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp,
+                                        ctypes.POINTER(vp)]
+    lib.qnn_free_weights.argtypes = [vp]
+    lib.qnn_weights_dequant.argtypes = [vp, vp, vp]
+    lib.qnn_conv2d_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
+    lib.qnn_dense_forward.argtypes = [vp, vp, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
+    for name in EXPORTS:   # every symbol the header declares must be exported
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != QNN_OK:
+        msg = load().qnn_last_error().decode(errors="replace")
+        raise QnnError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def last_kernel():
+    return load().qnn_last_kernel().decode()
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, what):
+    """The product path runs on the GPU only; fail loudly otherwise."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s: expected a torch.Tensor, got %r" % (what, type(t)))
+    if not t.is_cuda:
+        raise QnnError("%s: tensor is on %s; the low-bit engine has no CPU path" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s: expected float32, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(None)
+
+
+def per_word(store):
+    return {STORE_BIN: 32, STORE_I4: 8, STORE_I8: 4}[store]
+
+
+def words(store, channels):
+    pw = per_word(store)
+    return (channels + pw - 1) // pw
+
+
+def store_for_bits(bits):
+    """Packed storage able to hold signed `bits`-bit codes (2..8)."""
+    if bits <= 4:
+        return STORE_I4
+    if bits <= 8:
+        return STORE_I8
+    raise QnnError("no packed storage for %d-bit codes (max 8)" % bits)
+
+
+# ---------------------------------------------------------------------------
+# thin typed wrappers
+# ---------------------------------------------------------------------------
+def pack(x, channels, fn, nb, store):
+    """x: float32 (..., channels) CUDA -> int32 tensor (pixels, words)."""
+    x = require_cuda(x, "pack")
+    pixels = x.numel() // channels
+    out = torch.empty((pixels, words(store, channels)), dtype=torch.int32, device=x.device)
+    check(load().qnn_pack_f32(ptr(x), ptr(out), pixels, channels, fn, nb, store, stream_ptr()),
+          "qnn_pack_f32")
+    return out
+
+
+def unpack(p, pixels, channels, store, nb):
+    out = torch.empty((pixels, channels), dtype=torch.float32, device=p.device)
+    check(load().qnn_unpack_f32(ptr(p), ptr(out), pixels, channels, store, nb, stream_ptr()),
+          "qnn_unpack_f32")
+    return out
+
+
+class Weights:
+    """Owner of an opaque qnn_weights_t handle."""
+
+    def __init__(self, wkind, wbits, H, kernel, bias, stride, same_pad, store):
+        kernel = require_cuda(kernel, "prepack kernel")
+        if kernel.dim() == 2:
+            kh = kw = 1
+            cin, cout = kernel.shape
+        else:
+            kh, kw, cin, cout = kernel.shape
+        bias = require_cuda(bias, "prepack bias") if bias is not None else None
+        self.shape = (kh, kw, cin, cout)
+        self.store = store
+        self.stride = stride
+        self.same_pad = same_pad
+        self.handle = ctypes.c_void_p(None)
+        check(load().qnn_prepack_weights(wkind, wbits, float(H), ptr(kernel), kh, kw, cin, cout,
+                                         ptr(bias), stride, 1 if same_pad else 0, store,
+                                         stream_ptr(), ctypes.byref(self.handle)),
+              "qnn_prepack_weights")
+        self.device = kernel.device
+
+    def dequant(self):
+        kh, kw, cin, cout = self.shape
+        out = torch.empty((kh, kw, cin, cout), dtype=torch.float32, device=self.device)
+        check(load().qnn_weights_dequant(self.handle, ptr(out), stream_ptr()), "qnn_weights_dequant")
+        return out
+
+    def __del__(self):
+        try:
+            if self.handle and self.handle.value and _lib is not None:
+                _lib.qnn_free_weights(self.handle)
+                self.handle = ctypes.c_void_p(None)
+        except Exception:
+            pass
+
+
+def out_hw(size, k, stride, same_pad):
+    if same_pad:
+        return -(-size // stride)
+    return (size - k) // stride + 1
+
+
+def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
+           pool=1, out_store=STORE_F32):
+    """Run qnn_conv2d_forward; x is a float32 NHWC tensor or an int32 packed tensor.
+    Returns (y, Hp, Wp): y float32 (N,Hp,Wp,cout) or int32 (N*Hp*Wp, words)."""
+    kh, kw, cin, cout = w.shape
+    Ho = out_hw(H, kh, w.stride, w.same_pad) // pool
+    Wo = out_hw(W, kw, w.stride, w.same_pad) // pool
+    if out_store == STORE_F32:
+        y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty((N * Ho * Wo, words(out_store, cout)), dtype=torch.int32, device=x.device)
+    epi = Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store)
+    check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
+                                    ptr(y), stream_ptr()), "qnn_conv2d_forward")
+    return y, Ho, Wo
+
+
+def dense(w, x, x_store, x_bits, N, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
+          out_store=STORE_F32):
+    cout = w.shape[3]
+    if out_store == STORE_F32:
+        y = torch.empty((N, cout), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty((N, words(out_store, cout)), dtype=torch.int32, device=x.device)
+    epi = Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, 1, out_store)
+    check(load().qnn_dense_forward(w.handle, ptr(x), x_store, x_bits, N, ctypes.byref(epi), ptr(y),
+                                   stream_ptr()), "qnn_dense_forward")
+    return y

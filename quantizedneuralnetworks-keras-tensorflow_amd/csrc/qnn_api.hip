@@ -1,0 +1,25 @@
+// Library-level entry points: version, thread-local error / kernel-name strings.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "qnn_common.h"
+
+namespace {
+thread_local char g_error[512] = "";
+thread_local char g_kernel[64] = "";
+}  // namespace
+
+void qnn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+void qnn_set_kernel_name(const char* name) {
+    snprintf(g_kernel, sizeof(g_kernel), "%s", name);
+}
+
+extern "C" int qnn_version(void) { return QNN_ABI_VERSION; }
+extern "C" const char* qnn_last_error(void) { return g_error; }
+extern "C" const char* qnn_last_kernel(void) { return g_kernel; }

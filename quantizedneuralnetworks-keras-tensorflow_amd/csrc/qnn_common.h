@@ -1,0 +1,161 @@
+// Shared host/device helpers of the gfx950 low-bit forward engine.
+// Written for CDNA4 only (wave64); no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "qnn_abi.h"
+
+#define QNN_WAVE 64
+
+// ---- error plumbing --------------------------------------------------------
+void qnn_set_error(const char* fmt, ...);
+void qnn_set_kernel_name(const char* name);
+
+#define QNN_HIP(expr)                                                          \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) {                                                \
+            qnn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                          __FILE__, __LINE__);                                 \
+            return QNN_EHIP;                                                   \
+        }                                                                      \
+    } while (0)
+
+#define QNN_REQUIRE(cond, code, ...)                                           \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            qnn_set_error(__VA_ARGS__);                                        \
+            return (code);                                                     \
+        }                                                                      \
+    } while (0)
+
+// ---- opaque weights handle --------------------------------------------------
+struct qnn_weights {
+    int wkind, wbits;
+    float H;
+    int kh, kw, cin, cout;
+    int stride, same_pad;
+    int store;        // QNN_STORE_F32 (float path only) | BIN | I4 | I8
+    int cw;           // packed words per tap (ceil(cin / per_word))
+    int kwords;       // kh*kw*cw
+    int wshift;       // quantized value = code * 2^-wshift
+    uint32_t* d_packed;   // [cout][kh*kw][cw]   packed codes (store != F32)
+    float* d_wq;          // [cout][kh*kw][cin]  quantized values as float32
+    float* d_bias;        // [cout] or nullptr
+    int32_t* d_corr;      // BIN + same_pad: [64][cout] zero-padding corrections
+};
+
+// ---- geometry shared by every conv kernel ------------------------------------
+struct ConvGeom {
+    int N, H, W, Ho, Wo;       // Ho/Wo: conv output (before pooling)
+    int cin, cout, kh, kw, stride;
+    int pt, pl;                // SAME padding before (top/left)
+    int cw, kwords;
+    int pool;                  // 1 or 2
+    int Hp, Wp;                // stored output size (Ho/pool, Wo/pool)
+};
+
+struct EpiArgs {
+    const float* bias;         // or nullptr
+    const float* bn_inv;       // or nullptr
+    const float* bn_shift;
+    float scale;               // 2^-(wshift+xshift)
+    float act_m;               // 2^(act_bits-1) for quantized_tanh
+    int fn;
+    int out_store;
+    int ocw;                   // words per stored output pixel (packed) or cout (f32)
+};
+
+#ifdef __HIPCC__
+#define QNN_HD __host__ __device__
+#else
+#define QNN_HD
+#endif
+
+QNN_HD static inline int qnn_per_word(int store) {
+    return store == QNN_STORE_BIN ? 32 : store == QNN_STORE_I4 ? 8 : store == QNN_STORE_I8 ? 4 : 1;
+}
+QNN_HD static inline int qnn_words(int store, int channels) {
+    int pw = qnn_per_word(store);
+    return (channels + pw - 1) / pw;
+}
+
+// TF 'SAME' padding (documented TF semantics; oracle: same_padding()).
+static inline void qnn_same_pad(int in, int k, int s, int same, int* out, int* before) {
+    if (same) {
+        *out = (in + s - 1) / s;
+        int total = (*out - 1) * s + k - in;
+        if (total < 0) total = 0;
+        *before = total / 2;
+    } else {
+        *out = (in - k) / s + 1;
+        *before = 0;
+    }
+}
+
+#ifdef __HIPCC__
+// ---- float32 activation clips, replayed op by op ------------------------------
+// All arithmetic uses the explicitly rounded intrinsics so that no FMA
+// contraction can change a rounding the reference performs.
+
+// binary_ops.py:16-24,8-13,37-51: 2*round_through(clip(0.5x+0.5,0,1)) - 1
+__device__ __forceinline__ float qnn_binary_tanh(float x) {
+    float h = __fadd_rn(__fmul_rn(0.5f, x), 0.5f);
+    h = fminf(fmaxf(h, 0.0f), 1.0f);
+    float r = rintf(h);                          // tf.round: half to even
+    float rt = __fadd_rn(h, __fsub_rn(r, h));    // x + stop_gradient(round(x) - x)
+    return __fsub_rn(__fmul_rn(2.0f, rt), 1.0f);
+}
+// the one bit of information in binary_tanh(x): 1 <=> +1
+__device__ __forceinline__ uint32_t qnn_binary_bit(float x) {
+    return qnn_binary_tanh(x) > 0.0f ? 1u : 0u;
+}
+// quantized_ops.py:49-66,87-100 in code units: clip(round_through(x*m), -m, m-1)
+__device__ __forceinline__ float qnn_quant_code_f(float x, float m) {
+    float t = __fmul_rn(x, m);
+    float r = rintf(t);
+    float rt = __fadd_rn(t, __fsub_rn(r, t));
+    return fminf(fmaxf(rt, -m), __fsub_rn(m, 1.0f));
+}
+__device__ __forceinline__ float qnn_quantized_tanh(float x, float m) {
+    return __fdiv_rn(qnn_quant_code_f(x, m), m);
+}
+
+// ---- dot products on packed words ----------------------------------------------
+// popcount(a ^ w): number of channels whose signs differ.
+__device__ __forceinline__ int qnn_dot_bin(uint32_t a, uint32_t w, int acc) {
+    return acc + __popc(a ^ w);
+}
+// 8 x (int4 * int4) + acc  -> v_dot8_i32_i4
+__device__ __forceinline__ int qnn_dot_i4(uint32_t a, uint32_t w, int acc) {
+    return __builtin_amdgcn_sdot8((int)a, (int)w, acc, false);
+}
+// 4 x (int8 * int8) + acc  -> v_dot4_i32_i8
+__device__ __forceinline__ int qnn_dot_i8(uint32_t a, uint32_t w, int acc) {
+    return __builtin_amdgcn_sdot4((int)a, (int)w, acc, false);
+}
+
+template <int STORE>
+__device__ __forceinline__ int qnn_dot(uint32_t a, uint32_t w, int acc) {
+    if constexpr (STORE == QNN_STORE_BIN) return qnn_dot_bin(a, w, acc);
+    else if constexpr (STORE == QNN_STORE_I4) return qnn_dot_i4(a, w, acc);
+    else return qnn_dot_i8(a, w, acc);
+}
+
+// ---- epilogue: acc -> float value in the reference's op order -------------------
+__device__ __forceinline__ float qnn_epi_value(float v, int c, const EpiArgs& e) {
+    if (e.bias) v = __fadd_rn(v, e.bias[c]);
+    if (e.bn_inv) v = __fadd_rn(__fmul_rn(v, e.bn_inv[c]), e.bn_shift[c]);
+    return v;
+}
+// value -> stored code (BIN: 0/1; I4/I8: signed code) or float bits
+__device__ __forceinline__ int qnn_epi_code(float v, const EpiArgs& e) {
+    if (e.fn == QNN_FN_BINARY_TANH) {
+        const int b = (int)qnn_binary_bit(v);
+        return e.out_store == QNN_STORE_BIN ? b : 2 * b - 1;   // +-1 as a signed code
+    }
+    return (int)qnn_quant_code_f(v, e.act_m);
+}
+#endif  // __HIPCC__

@@ -1,0 +1,631 @@
+// Low-bit convolution / dense contractions for gfx950.
+//
+// Reference ops replaced: BinaryConv2D.call (layers/binary_layers.py:160-187),
+// QuantizedConv2D.call (layers/quantized_layers.py:164-194), BinaryDense.call
+// (binary_layers.py:78-85), QuantizedDense.call (quantized_layers.py:79-88) and the
+// weight quantizers binarize / quantize (binary_ops.py:54-64, quantized_ops.py:49-66),
+// plus, fused behind them, bias_add, inference BatchNormalization, the activation
+// clip and MaxPooling2D of models/vgg.py:15-42.
+//
+// Two kernel families:
+//   k_conv_ps       "pixel-stationary": one lane owns one output pixel and keeps
+//                   that pixel's whole receptive field (kh*kw*cw packed words) in
+//                   VGPRs; the wave walks the output channels and receives each
+//                   filter through SCALAR loads (the filter address is wave-uniform),
+//                   so the inner loop is v_xor+v_bcnt / v_dot8 / v_dot4 with an SGPR
+//                   operand and no LDS or vector-memory traffic at all.  2x2 max-pool
+//                   is a DPP quad reduction (lanes 4q..4q+3 hold one pool window);
+//                   packed outputs are assembled in a register and stored once.
+//   k_conv_generic  one thread per stored output element/word, runtime loops; any
+//                   shape, any stride, float32 inputs; the correctness fallback.
+#include "qnn_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------
+// weights: quantize + pack on device (once per set_weights)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float quantize_weight(float w, int wkind, float H, float m) {
+    if (wkind == QNN_W_BINARY) return __fmul_rn(H, qnn_binary_tanh(__fdiv_rn(w, H)));
+    if (wkind == QNN_W_QUANT) return qnn_quantized_tanh(w, m);
+    return w;
+}
+
+// d_wq[c][t][ci] = quantizer(kernel_hwio[t][ci][c])
+__global__ __launch_bounds__(kBlock) void k_prepack_float(const float* __restrict__ kernel,
+                                                          float* __restrict__ wq, int taps,
+                                                          int cin, int cout, int wkind, float H,
+                                                          float m) {
+    const int total = cout * taps * cin;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const int ci = i % cin;
+        const int t = (i / cin) % taps;
+        const int c = i / (cin * taps);
+        wq[i] = quantize_weight(kernel[((size_t)t * cin + ci) * cout + c], wkind, H, m);
+    }
+}
+
+// d_packed[c][t][w]: codes of the quantized values
+template <int STORE>
+__global__ __launch_bounds__(kBlock) void k_prepack_codes(const float* __restrict__ wq,
+                                                          uint32_t* __restrict__ packed, int taps,
+                                                          int cin, int cout, int cw, float code_m) {
+    constexpr int PW = (STORE == QNN_STORE_BIN) ? 32 : (STORE == QNN_STORE_I4) ? 8 : 4;
+    constexpr int BITS = 32 / PW;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const int total = cout * taps * cw;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const int w = i % cw;
+        const int ct = i / cw;   // c*taps + t
+        const float* src = wq + (size_t)ct * cin + w * PW;
+        const int left = cin - w * PW;
+        uint32_t out = 0;
+        for (int j = 0; j < PW && j < left; ++j) {
+            uint32_t code;
+            if constexpr (STORE == QNN_STORE_BIN) code = src[j] > 0.0f ? 1u : 0u;
+            else code = (uint32_t)(int)__fmul_rn(src[j], code_m);
+            out |= (code & MASK) << (j * BITS);
+        }
+        packed[i] = out;
+    }
+}
+
+// BIN zero-padding corrections.  Out-of-image taps are fed as all-zero words
+// (= every channel -1), so their spurious contribution sum_c (-1)*w_c must be
+// removed: corr[rmask*8+cmask][c] = sum over taps (dy,dx) with dy in rmask or dx in
+// cmask of sum_ci sign(w[dy][dx][ci][c]).
+__global__ __launch_bounds__(kBlock) void k_corr_table(const float* __restrict__ wq,
+                                                       int32_t* __restrict__ corr, int kh, int kw,
+                                                       int cin, int cout) {
+    const int total = 64 * cout;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const int c = i % cout;
+        const int cls = i / cout;
+        const int rmask = cls >> 3, cmask = cls & 7;
+        int s = 0;
+        for (int dy = 0; dy < kh; ++dy)
+            for (int dx = 0; dx < kw; ++dx) {
+                if (!(((rmask >> dy) & 1) | ((cmask >> dx) & 1))) continue;
+                const float* src = wq + ((size_t)c * kh * kw + dy * kw + dx) * cin;
+                for (int ci = 0; ci < cin; ++ci) s += src[ci] > 0.0f ? 1 : -1;
+            }
+        corr[i] = s;
+    }
+}
+
+// d_wq[c][t][ci] -> HWIO float32 (tests)
+__global__ __launch_bounds__(kBlock) void k_dequant_hwio(const float* __restrict__ wq,
+                                                         float* __restrict__ kernel, int taps,
+                                                         int cin, int cout) {
+    const int total = cout * taps * cin;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const int ci = i % cin;
+        const int t = (i / cin) % taps;
+        const int c = i / (cin * taps);
+        kernel[((size_t)t * cin + ci) * cout + c] = wq[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// generic kernel
+// ---------------------------------------------------------------------------
+// conv result (before bias) of output channel c at conv pixel (n, oy, ox)
+__device__ float conv_point(const ConvGeom& g, int x_store, const void* __restrict__ x,
+                            const uint32_t* __restrict__ wp, const float* __restrict__ wq,
+                            float scale, int n, int oy, int ox, int c) {
+    if (x_store == QNN_STORE_F32) {
+        const float* xf = (const float*)x;
+        float acc = 0.0f;
+        for (int dy = 0; dy < g.kh; ++dy) {
+            const int iy = oy * g.stride + dy - g.pt;
+            if ((unsigned)iy >= (unsigned)g.H) continue;
+            for (int dx = 0; dx < g.kw; ++dx) {
+                const int ix = ox * g.stride + dx - g.pl;
+                if ((unsigned)ix >= (unsigned)g.W) continue;
+                const float* a = xf + (((size_t)n * g.H + iy) * g.W + ix) * g.cin;
+                const float* w = wq + ((size_t)c * g.kh * g.kw + dy * g.kw + dx) * g.cin;
+                for (int ci = 0; ci < g.cin; ++ci) acc = fmaf(a[ci], w[ci], acc);
+            }
+        }
+        return acc;
+    }
+    const uint32_t* xa = (const uint32_t*)x;
+    int acc = 0;
+    for (int dy = 0; dy < g.kh; ++dy) {
+        const int iy = oy * g.stride + dy - g.pt;
+        if ((unsigned)iy >= (unsigned)g.H) continue;
+        for (int dx = 0; dx < g.kw; ++dx) {
+            const int ix = ox * g.stride + dx - g.pl;
+            if ((unsigned)ix >= (unsigned)g.W) continue;
+            const uint32_t* a = xa + (((size_t)n * g.H + iy) * g.W + ix) * g.cw;
+            const uint32_t* w = wp + ((size_t)c * g.kh * g.kw + dy * g.kw + dx) * g.cw;
+            if (x_store == QNN_STORE_BIN) {
+                int p = 0;
+                for (int j = 0; j < g.cw; ++j) p += __popc(a[j] ^ w[j]);
+                acc += g.cin - 2 * p;   // pad bits are 0 in both operands
+            } else if (x_store == QNN_STORE_I4) {
+                for (int j = 0; j < g.cw; ++j) acc = qnn_dot_i4(a[j], w[j], acc);
+            } else {
+                for (int j = 0; j < g.cw; ++j) acc = qnn_dot_i8(a[j], w[j], acc);
+            }
+        }
+    }
+    return __fmul_rn((float)acc, scale);
+}
+
+// one thread per stored output slot: (stored pixel, cout) for float32 outputs,
+// (stored pixel, word) for packed outputs
+__global__ __launch_bounds__(kBlock) void k_conv_generic(ConvGeom g, EpiArgs e, int x_store,
+                                                         const void* __restrict__ x,
+                                                         const uint32_t* __restrict__ wp,
+                                                         const float* __restrict__ wq,
+                                                         void* __restrict__ y) {
+    const int slots = e.ocw;
+    const size_t total = (size_t)g.N * g.Hp * g.Wp * slots;
+    const int pw = qnn_per_word(e.out_store);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * kBlock) {
+        const int slot = (int)(i % slots);
+        const size_t q = i / slots;
+        const int px = (int)(q % g.Wp);
+        const int py = (int)((q / g.Wp) % g.Hp);
+        const int n = (int)(q / ((size_t)g.Wp * g.Hp));
+        if (e.out_store == QNN_STORE_F32) {
+            const int c = slot;
+            float best = 0.0f;
+            for (int s = 0; s < g.pool * g.pool; ++s) {
+                const int oy = py * g.pool + s / g.pool, ox = px * g.pool + s % g.pool;
+                float v = conv_point(g, x_store, x, wp, wq, e.scale, n, oy, ox, c);
+                v = qnn_epi_value(v, c, e);
+                if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
+                else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
+                best = (s == 0) ? v : fmaxf(best, v);
+            }
+            ((float*)y)[i] = best;
+        } else {
+            const int bits = 32 / pw;
+            const uint32_t mask = (1u << bits) - 1u;
+            uint32_t word = 0;
+            for (int b = 0; b < pw; ++b) {
+                const int c = slot * pw + b;
+                if (c >= g.cout) break;
+                int best = 0;
+                for (int s = 0; s < g.pool * g.pool; ++s) {
+                    const int oy = py * g.pool + s / g.pool, ox = px * g.pool + s % g.pool;
+                    float v = conv_point(g, x_store, x, wp, wq, e.scale, n, oy, ox, c);
+                    v = qnn_epi_value(v, c, e);
+                    const int code = qnn_epi_code(v, e);
+                    best = (s == 0) ? code : max(best, code);
+                }
+                word |= ((uint32_t)best & mask) << (b * bits);
+            }
+            ((uint32_t*)y)[i] = word;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pixel-stationary kernel
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int quad_max_i(int v) {
+    int t = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v = max(v, t);
+    t = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    return max(v, t);
+}
+__device__ __forceinline__ float quad_max_f(float v) {
+    float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v = fmaxf(v, t);
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    return fmaxf(v, t);
+}
+
+// XS  : storage of x (QNN_STORE_F32 = float32 input, CW = cin floats per tap)
+// CW  : words per tap;  K : square kernel size;  OUT : storage of y
+template <int XS, int CW, int K, int OUT>
+__global__ __launch_bounds__(kBlock) void k_conv_ps(ConvGeom g, EpiArgs e,
+                                                    const uint32_t* __restrict__ x,
+                                                    const uint32_t* __restrict__ wts,
+                                                    const int32_t* __restrict__ corr,
+                                                    void* __restrict__ y) {
+    constexpr int KWORDS = K * K * CW;
+    constexpr int PWO = (OUT == QNN_STORE_BIN) ? 32 : (OUT == QNN_STORE_I4) ? 8 : 4;  // F32: 4 floats
+    constexpr int OBITS = (OUT == QNN_STORE_F32) ? 32 : 32 / PWO;
+
+    // ---- lane -> conv pixel (pool windows occupy aligned lane quads) ----
+    const long gl = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long total_q = (long)g.N * g.Hp * g.Wp;
+    const long q0 = (g.pool == 2) ? (gl >> 2) : gl;
+    const int sub = (g.pool == 2) ? (int)(gl & 3) : 0;
+    const bool live = q0 < total_q;
+    const long q = live ? q0 : total_q - 1;
+    const int px = (int)(q % g.Wp);
+    const int py = (int)((q / g.Wp) % g.Hp);
+    const int n = (int)(q / ((long)g.Wp * g.Hp));
+    const int oy = py * g.pool + (sub >> 1);
+    const int ox = px * g.pool + (sub & 1);
+
+    // ---- this pixel's receptive field into registers ----
+    uint32_t a[KWORDS];
+    int rmask = 0, cmask = 0;
+#pragma unroll
+    for (int dy = 0; dy < K; ++dy) {
+        const int iy = oy * g.stride + dy - g.pt;
+        const bool rin = (unsigned)iy < (unsigned)g.H;
+        if (!rin) rmask |= 1 << dy;
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+            const int ix = ox * g.stride + dx - g.pl;
+            const bool cin_ = (unsigned)ix < (unsigned)g.W;
+            if (dy == 0 && !cin_) cmask |= 1 << dx;
+            const bool inb = rin && cin_;
+            const uint32_t* p = x + (((long)n * g.H + (inb ? iy : 0)) * g.W + (inb ? ix : 0)) * CW;
+            if constexpr (CW % 4 == 0) {
+#pragma unroll
+                for (int j = 0; j < CW; j += 4) {
+                    uint4 v = inb ? *reinterpret_cast<const uint4*>(p + j) : make_uint4(0, 0, 0, 0);
+                    a[(dy * K + dx) * CW + j + 0] = v.x;
+                    a[(dy * K + dx) * CW + j + 1] = v.y;
+                    a[(dy * K + dx) * CW + j + 2] = v.z;
+                    a[(dy * K + dx) * CW + j + 3] = v.w;
+                }
+            } else if constexpr (CW % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < CW; j += 2) {
+                    uint2 v = inb ? *reinterpret_cast<const uint2*>(p + j) : make_uint2(0, 0);
+                    a[(dy * K + dx) * CW + j + 0] = v.x;
+                    a[(dy * K + dx) * CW + j + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CW; ++j) a[(dy * K + dx) * CW + j] = inb ? p[j] : 0u;
+            }
+        }
+    }
+    const int cls = rmask * 8 + cmask;
+    const int ktot = K * K * g.cin;
+
+    // ---- walk the output channels; filters arrive through scalar loads ----
+    for (int c0 = 0; c0 < g.cout; c0 += PWO) {
+        uint32_t word = 0;
+        float fv[4];
+#pragma unroll(OUT == QNN_STORE_F32 ? 4 : 2)
+        for (int b = 0; b < PWO; ++b) {
+            const int c = c0 + b;
+            const uint32_t* w = wts + (long)c * KWORDS;
+            float v;
+            if constexpr (XS == QNN_STORE_F32) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KWORDS; ++k)
+                    acc = fmaf(__uint_as_float(a[k]), __uint_as_float(w[k]), acc);
+                v = acc;
+            } else {
+                int acc = 0;
+#pragma unroll
+                for (int k = 0; k < KWORDS; ++k) acc = qnn_dot<XS>(a[k], w[k], acc);
+                if constexpr (XS == QNN_STORE_BIN) {
+                    acc = ktot - 2 * acc;
+                    if (corr) acc += corr[cls * g.cout + c];
+                }
+                v = __fmul_rn((float)acc, e.scale);
+            }
+            v = qnn_epi_value(v, c, e);
+            if constexpr (OUT == QNN_STORE_F32) {
+                if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
+                else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
+                if (g.pool == 2) v = quad_max_f(v);
+                fv[b] = v;
+            } else {
+                int code = qnn_epi_code(v, e);
+                if (g.pool == 2) code = quad_max_i(code);
+                word |= ((uint32_t)code & ((OBITS == 32) ? 0xffffffffu : ((1u << OBITS) - 1u)))
+                        << (b * OBITS);
+            }
+        }
+        if (live && sub == 0) {
+            if constexpr (OUT == QNN_STORE_F32)
+                *reinterpret_cast<float4*>((float*)y + q * g.cout + c0) =
+                    make_float4(fv[0], fv[1], fv[2], fv[3]);
+            else
+                ((uint32_t*)y)[q * e.ocw + c0 / PWO] = word;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------
+template <int XS, int CW, int K>
+int launch_ps_out(const ConvGeom& g, const EpiArgs& e, const void* x, const uint32_t* wts,
+                  const int32_t* corr, void* y, hipStream_t s) {
+    const long lanes = (long)g.N * g.Hp * g.Wp * (g.pool == 2 ? 4 : 1);
+    const dim3 grid((unsigned)((lanes + kBlock - 1) / kBlock)), block(kBlock);
+    const uint32_t* xu = (const uint32_t*)x;
+    switch (e.out_store) {
+        case QNN_STORE_F32:
+            hipLaunchKernelGGL((k_conv_ps<XS, CW, K, QNN_STORE_F32>), grid, block, 0, s, g, e, xu, wts, corr, y);
+            break;
+        case QNN_STORE_BIN:
+            hipLaunchKernelGGL((k_conv_ps<XS, CW, K, QNN_STORE_BIN>), grid, block, 0, s, g, e, xu, wts, corr, y);
+            break;
+        case QNN_STORE_I4:
+            hipLaunchKernelGGL((k_conv_ps<XS, CW, K, QNN_STORE_I4>), grid, block, 0, s, g, e, xu, wts, corr, y);
+            break;
+        case QNN_STORE_I8:
+            hipLaunchKernelGGL((k_conv_ps<XS, CW, K, QNN_STORE_I8>), grid, block, 0, s, g, e, xu, wts, corr, y);
+            break;
+        default:
+            return 1;
+    }
+    return 0;
+}
+
+// returns 0 if a pixel-stationary instantiation was launched, 1 if none fits
+int try_launch_ps(const ConvGeom& g, const EpiArgs& e, int x_store, const void* x,
+                  const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len) {
+    if (g.kh != g.kw || (g.kh != 3 && g.kh != 1)) return 1;
+    const int pwo = e.out_store == QNN_STORE_F32 ? 4 : qnn_per_word(e.out_store);
+    if (g.cout % pwo != 0) return 1;
+    if (g.pool != 1 && g.pool != 2) return 1;
+    const uint32_t* wts = x_store == QNN_STORE_F32 ? (const uint32_t*)w->d_wq : w->d_packed;
+    const int32_t* corr = (x_store == QNN_STORE_BIN && w->same_pad && g.kh == 3) ? w->d_corr : nullptr;
+    const int cw = x_store == QNN_STORE_F32 ? g.cin : g.cw;
+    const char* xs = x_store == QNN_STORE_F32 ? "f32" : x_store == QNN_STORE_BIN ? "bin"
+                     : x_store == QNN_STORE_I4 ? "i4" : "i8";
+    snprintf(name, name_len, "ps_%s_cw%d_k%d", xs, cw, g.kh);
+#define PS_CASE(XS, CW, K)                                                     \
+    if (x_store == XS && cw == CW && g.kh == K)                                \
+        return launch_ps_out<XS, CW, K>(g, e, x, wts, corr, y, s);
+    PS_CASE(QNN_STORE_F32, 1, 3)
+    PS_CASE(QNN_STORE_F32, 3, 3)
+    PS_CASE(QNN_STORE_BIN, 1, 3)
+    PS_CASE(QNN_STORE_BIN, 2, 3)
+    PS_CASE(QNN_STORE_BIN, 4, 3)
+    PS_CASE(QNN_STORE_BIN, 8, 3)
+    PS_CASE(QNN_STORE_BIN, 1, 1)
+    PS_CASE(QNN_STORE_BIN, 2, 1)
+    PS_CASE(QNN_STORE_I4, 2, 3)
+    PS_CASE(QNN_STORE_I4, 4, 3)
+    PS_CASE(QNN_STORE_I4, 8, 3)
+    PS_CASE(QNN_STORE_I4, 16, 3)
+    PS_CASE(QNN_STORE_I4, 2, 1)
+    PS_CASE(QNN_STORE_I4, 4, 1)
+    PS_CASE(QNN_STORE_I4, 8, 1)
+    PS_CASE(QNN_STORE_I8, 4, 3)
+    PS_CASE(QNN_STORE_I8, 8, 3)
+    PS_CASE(QNN_STORE_I8, 16, 3)
+#undef PS_CASE
+    return 1;
+}
+
+int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, EpiArgs* e) {
+    e->bias = w->d_bias;
+    e->bn_inv = epi->bn_inv;
+    e->bn_shift = epi->bn_shift;
+    QNN_REQUIRE((epi->bn_inv == nullptr) == (epi->bn_shift == nullptr), QNN_EINVAL,
+                "epilogue: bn_inv and bn_shift must both be set or both be NULL");
+    e->scale = ldexpf(1.0f, -(w->wshift + xshift));
+    e->fn = epi->fn;
+    e->out_store = epi->out_store;
+    e->act_m = 1.0f;
+    QNN_REQUIRE(epi->fn == QNN_FN_NONE || epi->fn == QNN_FN_BINARY_TANH ||
+                    epi->fn == QNN_FN_QUANTIZED_TANH,
+                QNN_EINVAL, "epilogue: fn=%d cannot be fused", epi->fn);
+    if (epi->fn == QNN_FN_QUANTIZED_TANH) {
+        QNN_REQUIRE(epi->act_bits >= 2 && epi->act_bits <= 24, QNN_EINVAL,
+                    "epilogue: act_bits=%d", epi->act_bits);
+        e->act_m = (float)(1u << (epi->act_bits - 1));
+    }
+    switch (epi->out_store) {
+        case QNN_STORE_F32:
+            e->ocw = w->cout;
+            break;
+        case QNN_STORE_BIN:
+            QNN_REQUIRE(epi->fn == QNN_FN_BINARY_TANH, QNN_EINVAL,
+                        "epilogue: BIN output needs fn=binary_tanh");
+            e->ocw = qnn_words(QNN_STORE_BIN, w->cout);
+            break;
+        case QNN_STORE_I4:
+        case QNN_STORE_I8:
+            QNN_REQUIRE(epi->fn == QNN_FN_BINARY_TANH ||
+                            (epi->fn == QNN_FN_QUANTIZED_TANH && epi->act_bits <= epi->out_store),
+                        QNN_EINVAL, "epilogue: fn=%d act_bits=%d does not fit %d-bit output",
+                        epi->fn, epi->act_bits, epi->out_store);
+            e->ocw = qnn_words(epi->out_store, w->cout);
+            break;
+        default:
+            qnn_set_error("epilogue: out_store=%d", epi->out_store);
+            return QNN_EINVAL;
+    }
+    return QNN_OK;
+}
+
+int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, int N, int H,
+                 int W, const qnn_epilogue_t* epi, void* y, void* stream, bool dense) {
+    QNN_REQUIRE(w && x && y && epi, QNN_EINVAL, "conv_forward: null pointer");
+    QNN_REQUIRE(N >= 0 && H > 0 && W > 0, QNN_EINVAL, "conv_forward: N=%d H=%d W=%d", N, H, W);
+    int xshift = 0;
+    if (x_store == QNN_STORE_F32) {
+        // any float32 values; uses the float32 copy of the quantized kernel
+    } else {
+        QNN_REQUIRE(x_store == w->store, QNN_EINVAL,
+                    "conv_forward: x_store=%d but the weights were prepacked for store=%d",
+                    x_store, w->store);
+        if (x_store != QNN_STORE_BIN) {
+            QNN_REQUIRE(x_bits >= 1 && x_bits <= x_store, QNN_EINVAL,
+                        "conv_forward: x_bits=%d does not fit %d-bit storage", x_bits, x_store);
+            xshift = x_bits - 1;
+        }
+    }
+    ConvGeom g;
+    g.N = N; g.H = H; g.W = W;
+    g.cin = w->cin; g.cout = w->cout; g.kh = w->kh; g.kw = w->kw; g.stride = w->stride;
+    qnn_same_pad(H, w->kh, w->stride, w->same_pad, &g.Ho, &g.pt);
+    qnn_same_pad(W, w->kw, w->stride, w->same_pad, &g.Wo, &g.pl);
+    QNN_REQUIRE(g.Ho > 0 && g.Wo > 0, QNN_EINVAL, "conv_forward: empty output");
+    g.cw = w->cw; g.kwords = w->kwords;
+    g.pool = epi->pool;
+    QNN_REQUIRE(g.pool == 1 || g.pool == 2, QNN_EINVAL, "conv_forward: pool=%d", g.pool);
+    QNN_REQUIRE(!dense || g.pool == 1, QNN_EINVAL, "dense_forward: pool must be 1");
+    g.Hp = g.Ho / g.pool; g.Wp = g.Wo / g.pool;   // MaxPooling2D 'valid' drops the remainder
+    QNN_REQUIRE(g.Hp > 0 && g.Wp > 0, QNN_EINVAL, "conv_forward: pooled output is empty");
+    EpiArgs e;
+    int rc = check_epilogue(w, epi, xshift, &e);
+    if (rc != QNN_OK) return rc;
+    if (x_store == QNN_STORE_F32) e.scale = 1.0f;   // d_wq holds real values already
+    if (N == 0) return QNN_OK;
+
+    hipStream_t s = (hipStream_t)stream;
+    char name[64];
+    // the pixel-stationary kernel needs whole pool windows (even Ho/Wo are not
+    // required: the remainder row/column is simply never produced)
+    if (try_launch_ps(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0) {
+        qnn_set_kernel_name(name);
+    } else {
+        const size_t total = (size_t)g.N * g.Hp * g.Wp * e.ocw;
+        size_t blocks = (total + kBlock - 1) / kBlock;
+        if (blocks > 65535u * 16u) blocks = 65535u * 16u;
+        hipLaunchKernelGGL(k_conv_generic, dim3((unsigned)blocks), dim3(kBlock), 0, s, g, e, x_store,
+                           x, w->d_packed, w->d_wq, y);
+        qnn_set_kernel_name("generic");
+    }
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* kernel, int kh,
+                                   int kw, int cin, int cout, const float* bias, int stride,
+                                   int same_pad, int store, void* stream, qnn_weights_t** out) {
+    QNN_REQUIRE(kernel && out, QNN_EINVAL, "qnn_prepack_weights: null pointer");
+    QNN_REQUIRE(kh > 0 && kw > 0 && cin > 0 && cout > 0, QNN_EINVAL,
+                "qnn_prepack_weights: kernel shape (%d,%d,%d,%d)", kh, kw, cin, cout);
+    QNN_REQUIRE(kh <= 3 && kw <= 3, QNN_EUNSUPPORTED,
+                "qnn_prepack_weights: kernel %dx%d larger than 3x3 is not supported", kh, kw);
+    QNN_REQUIRE(stride >= 1, QNN_EINVAL, "qnn_prepack_weights: stride=%d", stride);
+    QNN_REQUIRE(wkind == QNN_W_FLOAT || wkind == QNN_W_BINARY || wkind == QNN_W_QUANT,
+                wkind == QNN_W_TERNARY ? QNN_EUNSUPPORTED : QNN_EINVAL,
+                "qnn_prepack_weights: wkind=%d not supported", wkind);
+    QNN_REQUIRE(H > 0.0f, QNN_EINVAL, "qnn_prepack_weights: H=%g", (double)H);
+    int wshift = 0;
+    float m = 1.0f;
+    if (wkind == QNN_W_QUANT) {
+        QNN_REQUIRE(wbits >= 2 && wbits <= 24, QNN_EINVAL, "qnn_prepack_weights: wbits=%d", wbits);
+        wshift = wbits - 1;
+        m = (float)(1u << wshift);
+    }
+    switch (store) {
+        case QNN_STORE_F32:
+            break;
+        case QNN_STORE_BIN:
+            QNN_REQUIRE(wkind == QNN_W_BINARY && H == 1.0f, QNN_EINVAL,
+                        "qnn_prepack_weights: BIN storage needs binary weights with H=1");
+            break;
+        case QNN_STORE_I4:
+        case QNN_STORE_I8:
+            QNN_REQUIRE((wkind == QNN_W_BINARY && H == 1.0f) ||
+                            (wkind == QNN_W_QUANT && wbits <= store),
+                        QNN_EINVAL, "qnn_prepack_weights: wkind=%d wbits=%d does not fit %d-bit storage",
+                        wkind, wbits, store);
+            break;
+        default:
+            qnn_set_error("qnn_prepack_weights: store=%d", store);
+            return QNN_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    qnn_weights* w = new (std::nothrow) qnn_weights();
+    QNN_REQUIRE(w, QNN_ENOMEM, "qnn_prepack_weights: host allocation failed");
+    *w = qnn_weights{};
+    w->wkind = wkind; w->wbits = wbits; w->H = H;
+    w->kh = kh; w->kw = kw; w->cin = cin; w->cout = cout;
+    w->stride = stride; w->same_pad = same_pad ? 1 : 0;
+    w->store = store; w->wshift = wshift;
+    w->cw = store == QNN_STORE_F32 ? cin : qnn_words(store, cin);
+    w->kwords = kh * kw * w->cw;
+    const int taps = kh * kw;
+    const size_t nq = (size_t)cout * taps * cin;
+#define PREPACK_HIP(expr)                                                      \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) {                                                \
+            qnn_set_error("%s failed: %s", #expr, hipGetErrorString(_e));      \
+            qnn_free_weights(w);                                               \
+            return _e == hipErrorOutOfMemory ? QNN_ENOMEM : QNN_EHIP;          \
+        }                                                                      \
+    } while (0)
+    PREPACK_HIP(hipMalloc(&w->d_wq, nq * sizeof(float)));
+    int grid = (int)((nq + kBlock - 1) / kBlock);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_prepack_float, dim3(grid), dim3(kBlock), 0, s, kernel, w->d_wq, taps, cin,
+                       cout, wkind, H, m);
+    if (bias) {
+        PREPACK_HIP(hipMalloc(&w->d_bias, cout * sizeof(float)));
+        PREPACK_HIP(hipMemcpyAsync(w->d_bias, bias, cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (store != QNN_STORE_F32) {
+        const size_t nw = (size_t)cout * w->kwords;
+        PREPACK_HIP(hipMalloc(&w->d_packed, nw * sizeof(uint32_t)));
+        grid = (int)((nw + kBlock - 1) / kBlock);
+        if (grid > 4096) grid = 4096;
+        if (store == QNN_STORE_BIN)
+            hipLaunchKernelGGL(k_prepack_codes<QNN_STORE_BIN>, dim3(grid), dim3(kBlock), 0, s, w->d_wq,
+                               w->d_packed, taps, cin, cout, w->cw, m);
+        else if (store == QNN_STORE_I4)
+            hipLaunchKernelGGL(k_prepack_codes<QNN_STORE_I4>, dim3(grid), dim3(kBlock), 0, s, w->d_wq,
+                               w->d_packed, taps, cin, cout, w->cw, m);
+        else
+            hipLaunchKernelGGL(k_prepack_codes<QNN_STORE_I8>, dim3(grid), dim3(kBlock), 0, s, w->d_wq,
+                               w->d_packed, taps, cin, cout, w->cw, m);
+        if (store == QNN_STORE_BIN && w->same_pad && (kh > 1 || kw > 1)) {
+            PREPACK_HIP(hipMalloc(&w->d_corr, (size_t)64 * cout * sizeof(int32_t)));
+            grid = (64 * cout + kBlock - 1) / kBlock;
+            hipLaunchKernelGGL(k_corr_table, dim3(grid), dim3(kBlock), 0, s, w->d_wq, w->d_corr, kh,
+                               kw, cin, cout);
+        }
+    }
+    PREPACK_HIP(hipGetLastError());
+#undef PREPACK_HIP
+    *out = w;
+    return QNN_OK;
+}
+
+extern "C" int qnn_free_weights(qnn_weights_t* w) {
+    if (!w) return QNN_OK;
+    if (w->d_packed) (void)hipFree(w->d_packed);
+    if (w->d_wq) (void)hipFree(w->d_wq);
+    if (w->d_bias) (void)hipFree(w->d_bias);
+    if (w->d_corr) (void)hipFree(w->d_corr);
+    delete w;
+    return QNN_OK;
+}
+
+extern "C" int qnn_weights_dequant(const qnn_weights_t* w, float* kernel_hwio, void* stream) {
+    QNN_REQUIRE(w && kernel_hwio, QNN_EINVAL, "qnn_weights_dequant: null pointer");
+    const int taps = w->kh * w->kw;
+    const size_t nq = (size_t)w->cout * taps * w->cin;
+    int grid = (int)((nq + kBlock - 1) / kBlock);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_dequant_hwio, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, w->d_wq,
+                       kernel_hwio, taps, w->cin, w->cout);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+extern "C" int qnn_conv2d_forward(const qnn_weights_t* w, const void* x, int x_store, int x_bits,
+                                  int N, int H, int W, const qnn_epilogue_t* epi, void* y,
+                                  void* stream) {
+    return conv_forward(w, x, x_store, x_bits, N, H, W, epi, y, stream, false);
+}
+
+extern "C" int qnn_dense_forward(const qnn_weights_t* w, const void* x, int x_store, int x_bits,
+                                 int N, const qnn_epilogue_t* epi, void* y, void* stream) {
+    QNN_REQUIRE(w, QNN_EINVAL, "qnn_dense_forward: null weights");
+    QNN_REQUIRE(w->kh == 1 && w->kw == 1, QNN_EINVAL,
+                "qnn_dense_forward: weights were prepacked as a %dx%d conv", w->kh, w->kw);
+    return conv_forward(w, x, x_store, x_bits, N, 1, 1, epi, y, stream, true);
+}

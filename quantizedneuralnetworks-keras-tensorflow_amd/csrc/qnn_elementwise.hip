@@ -1,0 +1,264 @@
+// Elementwise activation clips and pack/unpack kernels (HBM-bound streaming).
+//
+// Reference ops replaced: layers/binary_ops.py:37-51 (binary_tanh),
+// layers/quantized_ops.py:87-100 (quantized_tanh), layers/ternary_ops.py:15-54.
+// Each reference op is ~7 separate TF elementwise kernels (7 HBM round trips);
+// here it is one pass, 16 B per lane, grid-strided over <= 2048 blocks.
+#include "qnn_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 blocks (guide: grid sizing for streaming ops)
+
+inline int grid_for(size_t items) {
+    size_t b = (items + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------
+template <int FN>
+__global__ __launch_bounds__(kBlock) void k_act_f32(const float* __restrict__ x,
+                                                    float* __restrict__ y, size_t n, float m) {
+    const size_t n4 = n / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        float4 v = x4[i];
+        float4 r;
+        if constexpr (FN == QNN_FN_BINARY_TANH) {
+            r.x = qnn_binary_tanh(v.x); r.y = qnn_binary_tanh(v.y);
+            r.z = qnn_binary_tanh(v.z); r.w = qnn_binary_tanh(v.w);
+        } else {
+            r.x = qnn_quantized_tanh(v.x, m); r.y = qnn_quantized_tanh(v.y, m);
+            r.z = qnn_quantized_tanh(v.z, m); r.w = qnn_quantized_tanh(v.w, m);
+        }
+        y4[i] = r;
+    }
+    // tail (n % 4 elements)
+    const size_t t = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < n) {
+        if constexpr (FN == QNN_FN_BINARY_TANH) y[t] = qnn_binary_tanh(x[t]);
+        else y[t] = qnn_quantized_tanh(x[t], m);
+    }
+}
+
+// ternary_ops.py:52-54 + 15-30: pass 1 = sum |clip(x,-1,1)| in double
+__global__ __launch_bounds__(kBlock) void k_tern_sum(const float* __restrict__ x, size_t n,
+                                                     double* __restrict__ sum) {
+    double s = 0.0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        s += (double)fabsf(fminf(fmaxf(x[i], -1.0f), 1.0f));
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < kBlock / 64; ++i) t += part[i];
+        atomicAdd(sum, t);
+    }
+}
+// pass 2: W > cutoff -> 1, W <= -cutoff -> -1, else 0; then W + (Wt - W)
+__global__ __launch_bounds__(kBlock) void k_tern_apply(const float* __restrict__ x,
+                                                       float* __restrict__ y, size_t n,
+                                                       const double* __restrict__ sum) {
+    const float mean_abs = (float)(*sum / (double)n);
+    const float cutoff = __fmul_rn(0.7f, mean_abs);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float w = fminf(fmaxf(x[i], -1.0f), 1.0f);
+        float wt = w > cutoff ? 1.0f : (w <= -cutoff ? -1.0f : 0.0f);
+        y[i] = __fadd_rn(w, __fsub_rn(wt, w));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pack: one thread per output word; the thread's channels are contiguous in
+// NHWC so its loads are float4 when the channel count allows.
+template <int STORE>
+__device__ __forceinline__ uint32_t encode_one(float v, int fn, float m) {
+    if constexpr (STORE == QNN_STORE_BIN) {
+        if (fn == QNN_FN_GRID) return v > 0.0f ? 1u : 0u;
+        return qnn_binary_bit(v);
+    } else {
+        float code;
+        if (fn == QNN_FN_GRID) code = __fmul_rn(v, m);                 // already k/m
+        else if (fn == QNN_FN_BINARY_TANH) code = qnn_binary_tanh(v);  // +-1 as a code
+        else code = qnn_quant_code_f(v, m);
+        return (uint32_t)(int)code;
+    }
+}
+
+template <int STORE>
+__global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ x,
+                                                 uint32_t* __restrict__ y, size_t pixels,
+                                                 int channels, int cw, int fn, float m) {
+    constexpr int PW = (STORE == QNN_STORE_BIN) ? 32 : (STORE == QNN_STORE_I4) ? 8 : 4;
+    constexpr int BITS = 32 / PW;
+    constexpr uint32_t MASK = (BITS == 32) ? 0xffffffffu : ((1u << BITS) - 1u);
+    const size_t words = pixels * (size_t)cw;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const bool vec = (channels % PW) == 0;   // full words, 16-B aligned channel groups
+    for (size_t wi = (size_t)blockIdx.x * kBlock + threadIdx.x; wi < words; wi += stride) {
+        const size_t p = wi / cw;
+        const int w = (int)(wi - p * cw);
+        const float* src = x + p * (size_t)channels + (size_t)w * PW;
+        uint32_t out = 0;
+        if (vec) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+            for (int j = 0; j < PW / 4; ++j) {
+                float4 v = s4[j];
+                out |= (encode_one<STORE>(v.x, fn, m) & MASK) << ((4 * j + 0) * BITS);
+                out |= (encode_one<STORE>(v.y, fn, m) & MASK) << ((4 * j + 1) * BITS);
+                out |= (encode_one<STORE>(v.z, fn, m) & MASK) << ((4 * j + 2) * BITS);
+                out |= (encode_one<STORE>(v.w, fn, m) & MASK) << ((4 * j + 3) * BITS);
+            }
+        } else {
+            const int left = channels - w * PW;
+            for (int j = 0; j < PW && j < left; ++j)
+                out |= (encode_one<STORE>(src[j], fn, m) & MASK) << (j * BITS);
+        }
+        y[wi] = out;
+    }
+}
+
+template <int STORE>
+__global__ __launch_bounds__(kBlock) void k_unpack(const uint32_t* __restrict__ x,
+                                                   float* __restrict__ y, size_t pixels,
+                                                   int channels, int cw, float inv_m) {
+    constexpr int PW = (STORE == QNN_STORE_BIN) ? 32 : (STORE == QNN_STORE_I4) ? 8 : 4;
+    constexpr int BITS = 32 / PW;
+    const size_t n = pixels * (size_t)channels;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const size_t p = i / channels;
+        const int c = (int)(i - p * channels);
+        const uint32_t word = x[p * cw + c / PW];
+        const int sh = (c % PW) * BITS;
+        float v;
+        if constexpr (STORE == QNN_STORE_BIN) {
+            v = ((word >> sh) & 1u) ? 1.0f : -1.0f;
+        } else {
+            int code = (int)(word << (32 - BITS - sh)) >> (32 - BITS);   // sign-extend
+            v = __fmul_rn((float)code, inv_m);
+        }
+        y[i] = v;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" int qnn_binary_tanh_f32(const float* x, float* y, size_t n, void* stream) {
+    QNN_REQUIRE(x && y, QNN_EINVAL, "qnn_binary_tanh_f32: null pointer");
+    if (n == 0) return QNN_OK;
+    hipLaunchKernelGGL(k_act_f32<QNN_FN_BINARY_TANH>, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0,
+                       (hipStream_t)stream, x, y, n, 1.0f);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+extern "C" int qnn_quantized_tanh_f32(const float* x, float* y, size_t n, int nb, void* stream) {
+    QNN_REQUIRE(x && y, QNN_EINVAL, "qnn_quantized_tanh_f32: null pointer");
+    QNN_REQUIRE(nb >= 1 && nb <= 24, QNN_EINVAL, "qnn_quantized_tanh_f32: nb=%d out of range", nb);
+    if (n == 0) return QNN_OK;
+    const float m = (float)(1u << (nb - 1));
+    hipLaunchKernelGGL(k_act_f32<QNN_FN_QUANTIZED_TANH>, dim3(grid_for((n + 3) / 4)), dim3(kBlock),
+                       0, (hipStream_t)stream, x, y, n, m);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+extern "C" int qnn_ternary_tanh_f32(const float* x, float* y, size_t n, void* workspace16,
+                                    void* stream) {
+    QNN_REQUIRE(x && y && workspace16, QNN_EINVAL, "qnn_ternary_tanh_f32: null pointer");
+    if (n == 0) return QNN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    QNN_HIP(hipMemsetAsync(workspace16, 0, 16, s));
+    const int g = grid_for(n) < 1024 ? grid_for(n) : 1024;
+    hipLaunchKernelGGL(k_tern_sum, dim3(g), dim3(kBlock), 0, s, x, n, (double*)workspace16);
+    hipLaunchKernelGGL(k_tern_apply, dim3(grid_for(n)), dim3(kBlock), 0, s, x, y, n,
+                       (const double*)workspace16);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+extern "C" size_t qnn_packed_bytes(int store, size_t pixels, int channels) {
+    if (store == QNN_STORE_F32) return pixels * (size_t)channels * 4;
+    if (store != QNN_STORE_BIN && store != QNN_STORE_I4 && store != QNN_STORE_I8) return 0;
+    return pixels * (size_t)qnn_words(store, channels) * 4;
+}
+
+extern "C" int qnn_pack_f32(const float* x, void* y, size_t pixels, int channels, int fn, int nb,
+                            int store, void* stream) {
+    QNN_REQUIRE(x && y, QNN_EINVAL, "qnn_pack_f32: null pointer");
+    QNN_REQUIRE(channels > 0, QNN_EINVAL, "qnn_pack_f32: channels=%d", channels);
+    QNN_REQUIRE(fn == QNN_FN_BINARY_TANH || fn == QNN_FN_QUANTIZED_TANH || fn == QNN_FN_GRID,
+                QNN_EINVAL, "qnn_pack_f32: fn=%d cannot be encoded", fn);
+    if (pixels == 0) return QNN_OK;
+    const int cw = qnn_words(store, channels);
+    const size_t words = pixels * (size_t)cw;
+    float m = 1.0f;
+    if (store == QNN_STORE_BIN) {
+        QNN_REQUIRE(fn != QNN_FN_QUANTIZED_TANH, QNN_EINVAL,
+                    "qnn_pack_f32: BIN storage needs binary_tanh or grid input");
+    } else if (store == QNN_STORE_I4 || store == QNN_STORE_I8) {
+        if (fn != QNN_FN_BINARY_TANH) {
+            QNN_REQUIRE(nb >= (fn == QNN_FN_GRID ? 1 : 2) && nb <= store, QNN_EINVAL,
+                        "qnn_pack_f32: nb=%d does not fit %d-bit storage", nb, store);
+            m = (float)(1u << (nb - 1));
+        }
+    } else {
+        qnn_set_error("qnn_pack_f32: store=%d is not a packed kind", store);
+        return QNN_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_for(words);
+    if (store == QNN_STORE_BIN)
+        hipLaunchKernelGGL(k_pack<QNN_STORE_BIN>, dim3(g), dim3(kBlock), 0, s, x, (uint32_t*)y,
+                           pixels, channels, cw, fn, m);
+    else if (store == QNN_STORE_I4)
+        hipLaunchKernelGGL(k_pack<QNN_STORE_I4>, dim3(g), dim3(kBlock), 0, s, x, (uint32_t*)y,
+                           pixels, channels, cw, fn, m);
+    else
+        hipLaunchKernelGGL(k_pack<QNN_STORE_I8>, dim3(g), dim3(kBlock), 0, s, x, (uint32_t*)y,
+                           pixels, channels, cw, fn, m);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+extern "C" int qnn_unpack_f32(const void* x, float* y, size_t pixels, int channels, int store,
+                              int nb, void* stream) {
+    QNN_REQUIRE(x && y, QNN_EINVAL, "qnn_unpack_f32: null pointer");
+    QNN_REQUIRE(channels > 0, QNN_EINVAL, "qnn_unpack_f32: channels=%d", channels);
+    if (pixels == 0) return QNN_OK;
+    const int cw = qnn_words(store, channels);
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_for(pixels * (size_t)channels);
+    float inv_m = 1.0f;
+    if (store != QNN_STORE_BIN) {
+        QNN_REQUIRE(nb >= 1 && nb <= store, QNN_EINVAL, "qnn_unpack_f32: nb=%d vs store=%d", nb, store);
+        inv_m = 1.0f / (float)(1u << (nb - 1));
+    }
+    if (store == QNN_STORE_BIN)
+        hipLaunchKernelGGL(k_unpack<QNN_STORE_BIN>, dim3(g), dim3(kBlock), 0, s,
+                           (const uint32_t*)x, y, pixels, channels, cw, inv_m);
+    else if (store == QNN_STORE_I4)
+        hipLaunchKernelGGL(k_unpack<QNN_STORE_I4>, dim3(g), dim3(kBlock), 0, s,
+                           (const uint32_t*)x, y, pixels, channels, cw, inv_m);
+    else if (store == QNN_STORE_I8)
+        hipLaunchKernelGGL(k_unpack<QNN_STORE_I8>, dim3(g), dim3(kBlock), 0, s,
+                           (const uint32_t*)x, y, pixels, channels, cw, inv_m);
+    else {
+        qnn_set_error("qnn_unpack_f32: store=%d is not a packed kind", store);
+        return QNN_EINVAL;
+    }
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}

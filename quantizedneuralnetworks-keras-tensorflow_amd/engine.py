@@ -1,0 +1,440 @@
+"""Whole-network runners over a net spec (nets.py).
+
+  FusedModel   the production pipeline ("M1" traffic model): every
+               conv -> BN -> activation clip -> max-pool group is ONE kernel launch
+               whose epilogue writes the next layer's input already packed at the
+               activation width; inter-layer tensors never exist in float32.
+               Chains only (VGG); everything else goes through GraphModel.
+  GraphModel   general interpreter (ResNet: adds, 0.5 scaling, avg-pool, softmax).
+               Low-bit contractions run on the HIP kernels with the activation clip
+               fused into their pack-on-load and BN fused into their epilogue; the
+               stock Keras layers around them are elementwise torch ops on the GPU.
+  LayerModel   the Keras-compatible layer objects called one by one (float32 NHWC
+               in, float32 NHWC out per layer: "M0" traffic model).
+
+All three produce logits identical to each other; tests compare them with the CPU
+oracle.  None of them has a CPU path.
+"""
+import numpy as np
+import torch
+
+from . import _abi
+from .layers.binary_layers import BinaryConv2D, BinaryDense
+from .layers.quantized_layers import QuantizedConv2D, QuantizedDense
+from .layers import binary_ops, quantized_ops, ternary_ops
+
+F32 = np.float32
+
+
+def bn_constants(op):
+    """tf.nn.batch_normalization constants in float32, formed on the host exactly
+    as the oracle does: inv = (1/sqrt(var+eps))*gamma; shift = beta - mean*inv."""
+    gamma, beta, mean, var = (np.asarray(op[k], dtype=F32) for k in ("gamma", "beta", "mean", "var"))
+    inv = (F32(1) / np.sqrt(var + F32(op["eps"]))).astype(F32) * gamma
+    shift = beta - mean * inv
+    return inv.astype(F32), shift.astype(F32)
+
+
+def _wkind(op):
+    return {"binary": _abi.W_BINARY, "quantized": _abi.W_QUANT, "float": _abi.W_FLOAT}[op["kind"]]
+
+
+def _wstore(op):
+    """Narrowest packed storage of a contraction's weights (None for float)."""
+    if op["kind"] == "binary":
+        return _abi.STORE_BIN
+    if op["kind"] == "quantized" and op["nb"] <= 8:
+        return _abi.store_for_bits(op["nb"])
+    return None
+
+
+def _act_code(act):
+    """(fn, bits) of an activation op, or None if it is not a low-bit clip."""
+    if act is None:
+        return None
+    if act["fn"] == "binary_tanh":
+        return _abi.FN_BINARY_TANH, 1
+    if act["fn"] == "quantized_tanh" and act["nb"] <= 8:
+        return _abi.FN_QUANTIZED_TANH, int(act["nb"])
+    return None
+
+
+def _join_store(act_bits, wstore):
+    """Storage both operands of the next contraction are brought to."""
+    astore = _abi.STORE_BIN if act_bits == 1 else _abi.store_for_bits(act_bits)
+    if wstore is None:
+        return None
+    if astore == _abi.STORE_BIN and wstore == _abi.STORE_BIN:
+        return _abi.STORE_BIN
+    a = 0 if astore == _abi.STORE_BIN else astore
+    w = 0 if wstore == _abi.STORE_BIN else wstore
+    return max(a, w, _abi.STORE_I4)
+
+
+def _prepack(op, store, device, stride=1, same_pad=True):
+    kernel = torch.as_tensor(np.ascontiguousarray(op["kernel"], dtype=F32)).to(device)
+    bias = op.get("bias")
+    bias = torch.as_tensor(np.ascontiguousarray(bias, dtype=F32)).to(device) if bias is not None else None
+    return _abi.Weights(_wkind(op), int(op.get("nb", 1)), float(op.get("H", 1.0)), kernel, bias,
+                        stride, same_pad, store)
+
+
+# ---------------------------------------------------------------------------
+class FusedModel:
+    """Packed, fully fused pipeline for sequential specs (models/vgg.py topology)."""
+
+    def __init__(self, spec, device="cuda"):
+        self.device = torch.device(device)
+        self.steps = []
+        self._keep = []
+        groups = self._group(spec)
+        if groups is None:
+            raise _abi.QnnError("FusedModel: spec is not a fusable chain; use GraphModel")
+        x_store, x_bits = _abi.STORE_F32, 0
+        for gi, g in enumerate(groups):
+            op = g["op"]
+            nxt = groups[gi + 1]["op"] if gi + 1 < len(groups) else None
+            store_in = x_store
+            if store_in != _abi.STORE_F32 and _wstore(op) is None:
+                raise _abi.QnnError("FusedModel: float layer after a packed tensor")
+            w = _prepack(op, store_in, self.device, stride=g["stride"], same_pad=g["same"])
+            inv = shift = None
+            if g["bn"] is not None:
+                i, s = bn_constants(g["bn"])
+                inv = torch.as_tensor(i).to(self.device)
+                shift = torch.as_tensor(s).to(self.device)
+                self._keep += [inv, shift]
+            ac = _act_code(g["act"])
+            if g["act"] is not None and ac is None:
+                raise _abi.QnnError("FusedModel: activation %r cannot be fused" % g["act"]["fn"])
+            if ac is None:
+                fn, bits, out_store = _abi.FN_NONE, 0, _abi.STORE_F32
+                if nxt is not None:
+                    raise _abi.QnnError("FusedModel: layer without a low-bit activation mid-chain")
+            else:
+                fn, bits = ac
+                out_store = _join_store(bits, _wstore(nxt)) if nxt is not None else _abi.STORE_F32
+                if out_store is None:
+                    raise _abi.QnnError("FusedModel: float layer after a low-bit activation")
+            self.steps.append(dict(kind=g["kind"], w=w, x_store=x_store, x_bits=x_bits, inv=inv,
+                                   shift=shift, fn=fn, act_bits=bits if fn == _abi.FN_QUANTIZED_TANH else 0,
+                                   pool=g["pool"], out_store=out_store, softmax=g.get("softmax", False)))
+            x_store, x_bits = out_store, bits
+
+    @staticmethod
+    def _group(spec):
+        """[conv|dense] [bn] [act] [maxpool] ... -> list of groups, or None."""
+        groups, i, n = [], 0, len(spec)
+        seen_dense = False
+        while i < n:
+            op = spec[i]
+            if "src" in op and i > 0:
+                return None
+            if op["op"] == "flatten":
+                i += 1
+                continue
+            if op["op"] not in ("conv", "dense"):
+                return None
+            g = dict(op=op, kind=op["op"], bn=None, act=None, pool=1, stride=1, same=True)
+            if op["op"] == "conv":
+                if seen_dense:
+                    return None
+                st = tuple(op.get("strides", (1, 1)))
+                if st[0] != st[1]:
+                    return None
+                g["stride"] = st[0]
+                g["same"] = op.get("padding", "same") == "same"
+            else:
+                seen_dense = True
+            i += 1
+            if i < n and spec[i]["op"] == "bn":
+                g["bn"] = spec[i]; i += 1
+            if i < n and spec[i]["op"] == "act":
+                g["act"] = spec[i]; i += 1
+            if i < n and spec[i]["op"] == "maxpool":
+                if spec[i].get("size", 2) != 2 or g["kind"] != "conv":
+                    return None
+                g["pool"] = 2; i += 1
+            if i < n and spec[i]["op"] == "softmax":
+                g["softmax"] = True; i += 1
+            groups.append(g)
+        return groups
+
+    def forward(self, x):
+        """x: float32 NHWC CUDA tensor -> float32 (N, classes)."""
+        x = _abi.require_cuda(x, "FusedModel.forward")
+        N, H, W, _ = x.shape
+        cur = x
+        for st in self.steps:
+            if st["kind"] == "conv":
+                cur, H, W = _abi.conv2d(st["w"], cur, st["x_store"], st["x_bits"], N, H, W, st["inv"],
+                                        st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"])
+            else:
+                cur = _abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
+                                 st["fn"], st["act_bits"], st["out_store"])
+            if st["softmax"]:
+                cur = torch.softmax(cur, dim=-1)
+        return cur
+
+    __call__ = forward
+    predict = forward
+
+
+# ---------------------------------------------------------------------------
+class _Virtual:
+    """An activation clip that has not been materialised: (pre-activation, fn, nb)."""
+
+    def __init__(self, pre, fn, nb):
+        self.pre, self.fn, self.nb = pre, fn, nb
+        self._mat = None
+
+    def materialize(self):
+        if self._mat is None:
+            if self.fn == _abi.FN_BINARY_TANH:
+                self._mat = binary_ops.binary_tanh(self.pre)
+            else:
+                self._mat = quantized_ops.quantized_tanh(self.pre, self.nb)
+        return self._mat
+
+
+class GraphModel:
+    """General spec interpreter on the GPU (see module docstring)."""
+
+    def __init__(self, spec, device="cuda"):
+        self.device = torch.device(device)
+        self.spec = spec
+        self._weights = {}
+        self._bn = {}
+        # which ops consume each named tensor (to decide BN fusion)
+        self._names = []
+        for i, op in enumerate(spec):
+            self._names.append(op.get("dst", "t%d" % i))
+        self._consumers = {}
+        for i, op in enumerate(spec):
+            srcs = []
+            if op["op"] == "add":
+                srcs = [op["a"], op["b"]]
+            elif "src" in op:
+                srcs = [op["src"]]
+            elif i > 0:
+                srcs = [self._names[i - 1]]
+            else:
+                srcs = ["input"]
+            for s in srcs:
+                self._consumers.setdefault(s, []).append(i)
+        for i, op in enumerate(spec):
+            if op["op"] == "bn":
+                inv, shift = bn_constants(op)
+                self._bn[i] = (torch.as_tensor(inv).to(self.device), torch.as_tensor(shift).to(self.device))
+
+    def _get_weights(self, i, op, store):
+        key = (i, store)
+        if key not in self._weights:
+            st = tuple(op.get("strides", (1, 1)))
+            self._weights[key] = _prepack(op, store, self.device, stride=st[0],
+                                          same_pad=op.get("padding", "same") == "same")
+        return self._weights[key]
+
+    def _src(self, env, i, op):
+        if "src" in op:
+            return env[op["src"]]
+        return env[self._names[i - 1]] if i > 0 else env["input"]
+
+    @staticmethod
+    def _plain(t):
+        return t.materialize() if isinstance(t, _Virtual) else t
+
+    def forward(self, x):
+        x = _abi.require_cuda(x, "GraphModel.forward")
+        env = {"input": x}
+        skip = set()
+        spec = self.spec
+        for i, op in enumerate(spec):
+            if i in skip:
+                continue
+            kind = op["op"]
+            name = self._names[i]
+            if kind in ("conv", "dense"):
+                src = self._src(env, i, op)
+                # fuse an immediately following BN that is this tensor's only consumer
+                inv = shift = None
+                cons = self._consumers.get(name, [])
+                if len(cons) == 1 and spec[cons[0]]["op"] == "bn" and cons[0] == i + 1:
+                    inv, shift = self._bn[i + 1]
+                    skip.add(i + 1)
+                    name = self._names[i + 1]
+                wstore = _wstore(op)
+                if isinstance(src, _Virtual) and wstore is not None:
+                    bits = 1 if src.fn == _abi.FN_BINARY_TANH else src.nb
+                    store = _join_store(bits, wstore)
+                    pre = src.pre
+                    C = pre.shape[-1]
+                    xp = _abi.pack(pre, C, src.fn, src.nb if src.fn == _abi.FN_QUANTIZED_TANH else 1, store)
+                    w = self._get_weights(i, op, store)
+                    if kind == "conv":
+                        N, H, W, _ = pre.shape
+                        y, _, _ = _abi.conv2d(w, xp, store, bits, N, H, W, inv, shift)
+                    else:
+                        y = _abi.dense(w, xp, store, bits, pre.shape[0], inv, shift)
+                else:
+                    xin = self._plain(src)
+                    w = self._get_weights(i, op, _abi.STORE_F32)
+                    if kind == "conv":
+                        N, H, W, _ = xin.shape
+                        y, _, _ = _abi.conv2d(w, xin, _abi.STORE_F32, 0, N, H, W, inv, shift)
+                    else:
+                        y = _abi.dense(w, xin, _abi.STORE_F32, 0, xin.shape[0], inv, shift)
+                env[name] = y
+                continue
+            src = None if kind == "add" else self._src(env, i, op)
+            if kind == "bn":
+                inv, shift = self._bn[i]
+                y = self._plain(src) * inv + shift      # two roundings, as tf.nn.batch_normalization
+            elif kind == "act":
+                fn = op["fn"]
+                pre = self._plain(src)
+                if fn == "binary_tanh":
+                    y = _Virtual(pre, _abi.FN_BINARY_TANH, 1)
+                elif fn == "quantized_tanh" and op["nb"] <= 8:
+                    y = _Virtual(pre, _abi.FN_QUANTIZED_TANH, int(op["nb"]))
+                elif fn == "quantized_tanh":
+                    y = quantized_ops.quantized_tanh(pre, op["nb"])
+                elif fn == "ternary_tanh":
+                    y = ternary_ops.ternary_tanh(pre)
+                elif fn == "leaky_relu":
+                    y = torch.where(pre >= 0, pre, pre * F32(op.get("alpha", 0.3)))
+                else:
+                    raise ValueError(fn)
+            elif kind == "maxpool":
+                t = self._plain(src)
+                s = op.get("size", 2)
+                N, H, W, C = t.shape
+                y = t[:, :H // s * s, :W // s * s, :].reshape(N, H // s, s, W // s, s, C).amax(dim=(2, 4))
+            elif kind == "avgpool":
+                t = self._plain(src)
+                s = op.get("size", 8)
+                N, H, W, C = t.shape
+                win = t[:, :H // s * s, :W // s * s, :].reshape(N, H // s, s, W // s, s, C)
+                # window sums of grid values are exact in float64; one division in float32
+                y = (win.double().sum(dim=(2, 4)).float() / F32(s * s))
+            elif kind == "zeropad":
+                p = op["pad"]
+                y = torch.nn.functional.pad(self._plain(src), (0, 0, p, p, p, p))
+            elif kind == "flatten":
+                t = self._plain(src)
+                y = t.reshape(t.shape[0], -1)
+            elif kind == "add":
+                y = self._plain(env[op["a"]]) + self._plain(env[op["b"]])
+            elif kind == "scale":
+                y = self._plain(src) * F32(op["value"])
+            elif kind == "softmax":
+                y = torch.softmax(self._plain(src).double(), dim=-1).float()
+            else:
+                raise ValueError(kind)
+            env[name] = y
+        return self._plain(env[self._names[-1]])
+
+    __call__ = forward
+    predict = forward
+
+
+# ---------------------------------------------------------------------------
+class LayerModel:
+    """The spec instantiated as Keras-compatible layer objects, called one by one
+    (every low-bit layer: float32 NHWC in -> float32 NHWC out)."""
+
+    def __init__(self, spec, device="cuda", fuse_input_activation=True):
+        self.device = torch.device(device)
+        self.spec = spec
+        self.layers = {}
+        self._graph = GraphModel(spec, device)   # reuse name/consumer bookkeeping only
+        prev_act = {}
+        for i, op in enumerate(spec):
+            if op["op"] not in ("conv", "dense"):
+                continue
+            kw = dict(use_bias=op.get("bias") is not None, device=device)
+            if op["op"] == "conv":
+                kh, kw_, cin, cout = op["kernel"].shape
+                kw.update(kernel_size=(kh, kw_), strides=tuple(op.get("strides", (1, 1))),
+                          padding=op.get("padding", "same"))
+                if op["kind"] == "binary":
+                    layer = BinaryConv2D(cout, H=1., **kw)
+                elif op["kind"] == "quantized":
+                    layer = QuantizedConv2D(cout, H=1., nb=op["nb"], **kw)
+                else:
+                    raise _abi.QnnError("LayerModel covers the low-bit layers only")
+                layer.build((None, None, None, cin))
+            else:
+                cin, cout = op["kernel"].shape
+                if op["kind"] == "binary":
+                    layer = BinaryDense(cout, **kw)
+                elif op["kind"] == "quantized":
+                    layer = QuantizedDense(cout, nb=op["nb"], **kw)
+                else:
+                    raise _abi.QnnError("LayerModel covers the low-bit layers only")
+                layer.build((None, cin))
+            ws = [op["kernel"]] + ([op["bias"]] if op.get("bias") is not None else [])
+            layer.set_weights(ws)
+            self.layers[i] = layer
+        self.fuse_input_activation = fuse_input_activation
+
+    def forward(self, x):
+        x = _abi.require_cuda(x, "LayerModel.forward")
+        g = self._graph
+        env = {"input": x}
+        dom = {"input": None}     # what is known about each tensor's values
+        for i, op in enumerate(self.spec):
+            name = g._names[i]
+            kind = op["op"]
+            if kind == "add":
+                y = env[op["a"]] + env[op["b"]]
+                d = None
+            else:
+                sname = op["src"] if "src" in op else (g._names[i - 1] if i > 0 else "input")
+                src = env[sname]
+                d = None
+                if kind in ("conv", "dense"):
+                    layer = self.layers[i]
+                    layer.input_domain = dom.get(sname) if self.fuse_input_activation else None
+                    y = layer(src)
+                elif kind == "bn":
+                    inv, shift = g._bn[i]
+                    y = src * inv + shift
+                elif kind == "act":
+                    if op["fn"] == "binary_tanh":
+                        y = binary_ops.binary_tanh(src); d = "binary"
+                    elif op["fn"] == "quantized_tanh":
+                        y = quantized_ops.quantized_tanh(src, op["nb"])
+                        d = ("quantized", op["nb"]) if op["nb"] <= 8 else None
+                    elif op["fn"] == "ternary_tanh":
+                        y = ternary_ops.ternary_tanh(src)
+                    else:
+                        y = torch.where(src >= 0, src, src * F32(op.get("alpha", 0.3)))
+                elif kind == "maxpool":
+                    s = op.get("size", 2)
+                    N, H, W, C = src.shape
+                    y = src[:, :H // s * s, :W // s * s, :].reshape(N, H // s, s, W // s, s, C).amax(dim=(2, 4))
+                    d = dom.get(sname)      # max of grid values stays on the grid
+                elif kind == "avgpool":
+                    s = op.get("size", 8)
+                    N, H, W, C = src.shape
+                    win = src[:, :H // s * s, :W // s * s, :].reshape(N, H // s, s, W // s, s, C)
+                    y = win.double().sum(dim=(2, 4)).float() / F32(s * s)
+                elif kind == "zeropad":
+                    p = op["pad"]
+                    y = torch.nn.functional.pad(src, (0, 0, p, p, p, p))
+                elif kind == "flatten":
+                    y = src.reshape(src.shape[0], -1)
+                    d = dom.get(sname)
+                elif kind == "scale":
+                    y = src * F32(op["value"])
+                elif kind == "softmax":
+                    y = torch.softmax(src.double(), dim=-1).float()
+                else:
+                    raise ValueError(kind)
+            env[name] = y
+            dom[name] = d
+        return env[g._names[-1]]
+
+    __call__ = forward
+    predict = forward

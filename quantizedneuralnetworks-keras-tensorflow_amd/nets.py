@@ -1,0 +1,267 @@
+"""Topology builders for the benchmark configurations (callers of the hot path).
+
+Counterpart of models/model_factory.py:18-72, models/vgg.py:5-44 and
+models/resnet.py:15-147 plus the field names of utils/config_utils.py:10-46.
+A network is described as a *net spec*: a plain list of op dicts holding numpy
+arrays (Keras layouts).  The same spec is (a) interpreted by the CPU oracle,
+(b) instantiated as Keras-compatible layer objects (LayerModel) and (c) compiled
+into the fused packed pipeline (engine.FusedModel).
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+F32 = np.float32
+
+
+@dataclass
+class Config:
+    """Field names follow utils/config_utils.py:10-46 / config/config*.py."""
+    network_type: str = "full-qnn"      # float|qnn|full-qnn|bnn|qbnn|full-bnn
+    wbits: int = 4
+    abits: int = 4
+    architecture: str = "VGG"           # VGG | RESNET
+    dataset: str = "CIFAR-10"
+    dim: int = 32
+    channels: int = 3
+    classes: int = 10
+    nla: int = 1
+    nfa: int = 64
+    nlb: int = 1
+    nfb: int = 64
+    nlc: int = 1
+    nfc: int = 64
+    nres: int = 3
+    pfilt: int = 1
+    bits: Optional[int] = None
+
+    def __post_init__(self):
+        if self.bits is not None:       # config_utils.py:88-95
+            self.wbits = self.abits = int(self.bits)
+
+
+# The five BASELINE.json configurations (index = seed offset).
+def baseline_config(index):
+    if index == 0:   # MNIST full-bnn tiny
+        return Config(network_type="full-bnn", architecture="VGG", dataset="MNIST", dim=28,
+                      channels=1, nla=1, nlb=1, nlc=1, nfa=64, nfb=64, nfc=64)
+    if index == 1:   # CIFAR-10 VGG full-bnn
+        return Config(network_type="full-bnn", architecture="VGG")
+    if index == 2:   # CIFAR-10 VGG full-qnn 4/4 (headline)
+        return Config(network_type="full-qnn", wbits=4, abits=4, architecture="VGG")
+    if index == 3:   # CIFAR-10 VGG-large full-qnn 8/8
+        return Config(network_type="full-qnn", wbits=8, abits=8, architecture="VGG",
+                      nla=3, nlb=3, nlc=3, nfa=256, nfb=256, nfc=256)
+    if index == 4:   # ImageNet-224 ResNet nres=10 full-qnn 4/4
+        return Config(network_type="full-qnn", wbits=4, abits=4, architecture="RESNET",
+                      dataset="IMAGENET-224", dim=224, nres=10, pfilt=1)
+    raise ValueError(index)
+
+
+def _layer_kinds(cf):
+    """model_factory.py:24-61 -> (conv kind, conv nb, dense kind, dense nb, act op).
+
+    Quirk kept from the reference: the Dense layer of a (full-)qnn gets
+    nb=cf.abits, not cf.wbits (model_factory.py:31)."""
+    nt = cf.network_type
+    if nt == "float":
+        conv, fc, act = ("float", None), ("float", None), {"op": "act", "fn": "leaky_relu", "alpha": 0.3}
+    elif nt in ("qnn", "full-qnn"):
+        conv, fc = ("quantized", cf.wbits), ("quantized", cf.abits)
+        act = ({"op": "act", "fn": "leaky_relu", "alpha": 0.3} if nt == "qnn"
+               else {"op": "act", "fn": "quantized_tanh", "nb": cf.abits})
+    elif nt in ("bnn", "qbnn", "full-bnn"):
+        conv, fc = ("binary", None), ("binary", None)
+        if nt == "bnn":
+            act = {"op": "act", "fn": "leaky_relu", "alpha": 0.3}
+        elif nt == "qbnn":
+            act = {"op": "act", "fn": "quantized_tanh", "nb": cf.abits}
+        else:
+            act = {"op": "act", "fn": "binary_tanh"}
+    elif nt in ("tnn", "qtnn", "full-tnn"):
+        raise NotImplementedError("ternary layers are a 'next' row (SURVEY.md 8f.3)")
+    else:
+        raise ValueError("wrong network type, the supported network types in this repo are "
+                         "float, qnn, full-qnn, bnn and full-bnn")
+    return conv, fc, act
+
+
+def _klm(kh, kw, cin, cout):
+    return np.float32(1.0 / np.sqrt(1.5 / (int(cin * kh * kw) + int(cout * kh * kw))))
+
+
+class _ParamGen:
+    """Synthetic parameters, SURVEY.md 8d: latent kernels U(-1,1) (the reference's
+    own initializer, binary_layers.py:136), biases N(0,0.05), BN gamma U(.5,1.5),
+    beta N(0,.5), mean N(0,.1*sigma), variance ~ Var(conv output) estimated
+    analytically so post-BN activations have about unit variance."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+
+    def kernel(self, shape):
+        return self.rng.uniform(-1.0, 1.0, shape).astype(F32)
+
+    def bias(self, n):
+        return (self.rng.standard_normal(n) * 0.05).astype(F32)
+
+    def bn(self, n, var_est):
+        sigma = float(np.sqrt(var_est))
+        return {"gamma": self.rng.uniform(0.5, 1.5, n).astype(F32),
+                "beta": (self.rng.standard_normal(n) * 0.5).astype(F32),
+                "mean": (self.rng.standard_normal(n) * 0.1 * sigma).astype(F32),
+                "var": (var_est * self.rng.uniform(0.8, 1.25, n)).astype(F32)}
+
+
+def _w_var(kind, nb):
+    if kind == "binary":
+        return 1.0
+    if kind == "quantized":
+        m = 2.0 ** (nb - 1)
+        return ((2 * m) ** 2 - 1) / 12.0 / (m * m)
+    return 1.0 / 3.0
+
+
+def _act_second_moment(act):
+    if act is None:
+        return 1.0 / 3.0            # raw image, U[0,1]: E[x^2] = 1/3
+    if act["fn"] == "binary_tanh":
+        return 1.0
+    if act["fn"] == "quantized_tanh":
+        return 0.45                 # ~N(0,1) clipped to [-1,1)
+    return 0.6
+
+
+def _conv_op(gen, kind, nb, kh, cin, cout, strides, use_bias, prev_act):
+    op = {"op": "conv", "kind": kind, "kernel": gen.kernel((kh, kh, cin, cout)),
+          "bias": gen.bias(cout) if use_bias else None, "strides": (strides, strides),
+          "padding": "same", "klm": _klm(kh, kh, cin, cout)}
+    if kind == "quantized":
+        op["nb"] = int(nb)
+    var = kh * kh * cin * _act_second_moment(prev_act) * _w_var(kind, nb)
+    return op, var
+
+
+def vgg_spec(cf, seed=0):
+    """models/vgg.py:5-44."""
+    (ck, cnb), (fk, fnb), act = _layer_kinds(cf)
+    gen = _ParamGen(seed)
+    spec = []
+    cin, prev_act = cf.channels, None
+    size = cf.dim
+
+    def block(n_layers, filters):
+        nonlocal cin, prev_act
+        for _ in range(n_layers):
+            op, var = _conv_op(gen, ck, cnb, 3, cin, filters, 1, True, prev_act)
+            spec.append(op)
+            spec.append(dict(op="bn", eps=1e-4, **gen.bn(filters, var)))
+            spec.append(dict(act))
+            cin, prev_act = filters, act
+
+    block(1, cf.nfa)                    # vgg.py:15-17
+    block(cf.nla - 1, cf.nfa)           # vgg.py:19-22
+    spec.append({"op": "maxpool", "size": 2}); size //= 2
+    block(cf.nlb, cf.nfb)
+    spec.append({"op": "maxpool", "size": 2}); size //= 2
+    block(cf.nlc, cf.nfc)
+    spec.append({"op": "maxpool", "size": 2}); size //= 2
+    spec.append({"op": "flatten"})
+    k = size * size * cin
+    dense = {"op": "dense", "kind": fk, "kernel": gen.kernel((k, cf.classes)),
+             "bias": gen.bias(cf.classes)}
+    if fk == "quantized":
+        dense["nb"] = int(fnb)
+    spec.append(dense)
+    var = k * _act_second_moment(prev_act) * _w_var(fk, fnb)
+    spec.append(dict(op="bn", eps=1e-4, **gen.bn(cf.classes, var)))
+    return spec
+
+
+def resnet_spec(cf, seed=0):
+    """models/resnet.py:72-144 (ResNet v1, depth 6n+2, use_bias=False, 0.5*(x+y))."""
+    (ck, cnb), (fk, fnb), act = _layer_kinds(cf)
+    gen = _ParamGen(seed)
+    spec = []
+    uid = [0]
+
+    def name(prefix):
+        uid[0] += 1
+        return "%s%d" % (prefix, uid[0])
+
+    def resnet_layer(src, cin, filters, ksize=3, strides=1, bn=True, activation=True, prev_act=None):
+        op, var = _conv_op(gen, ck, cnb, ksize, cin, filters * cf.pfilt, strides, False, prev_act)
+        op["src"] = src
+        op["dst"] = name("c")
+        spec.append(op)
+        last = op["dst"]
+        if bn:
+            b = dict(op="bn", eps=1e-3, src=last, dst=name("b"), **gen.bn(filters * cf.pfilt, var))
+            spec.append(b)
+            last = b["dst"]
+        if activation:
+            a = dict(act)
+            a.update(src=last, dst=name("a"))
+            spec.append(a)
+            last = a["dst"]
+        return last
+
+    src = "input"
+    size = cf.dim
+    if cf.dataset in ("MNIST", "FASHION"):      # resnet.py:101-102
+        spec.append({"op": "zeropad", "pad": 2, "src": "input", "dst": "padded"})
+        src = "padded"
+        size += 4
+    num_filters = 16
+    x = resnet_layer(src, cf.channels, num_filters, prev_act=None)
+    cin = num_filters * cf.pfilt
+    for stack in range(3):
+        for res_block in range(cf.nres):
+            strides = 2 if (stack > 0 and res_block == 0) else 1
+            y = resnet_layer(x, cin, num_filters, strides=strides, prev_act=act)
+            y = resnet_layer(y, num_filters * cf.pfilt, num_filters, activation=False, prev_act=act)
+            if stack > 0 and res_block == 0:
+                x = resnet_layer(x, cin, num_filters, ksize=1, strides=strides, bn=False,
+                                 activation=False, prev_act=act)
+                size //= 2
+            s = name("s")
+            spec.append({"op": "add", "a": x, "b": y, "dst": s})
+            h = name("h")
+            spec.append({"op": "scale", "value": 0.5, "src": s, "dst": h})
+            a = dict(act)
+            a.update(src=h, dst=name("a"))
+            spec.append(a)
+            x = a["dst"]
+            cin = num_filters * cf.pfilt
+        num_filters *= 2
+    spec.append({"op": "avgpool", "size": 8, "src": x, "dst": "pooled"})
+    size //= 8
+    spec.append({"op": "flatten", "src": "pooled", "dst": "flat"})
+    k = size * size * cin
+    dense = {"op": "dense", "kind": fk, "kernel": gen.kernel((k, cf.classes)), "bias": None,
+             "src": "flat", "dst": "logits"}
+    if fk == "quantized":
+        dense["nb"] = int(fnb)
+    spec.append(dense)
+    spec.append({"op": "softmax", "src": "logits", "dst": "probs"})
+    return spec
+
+
+def build_spec(cf, seed=0):
+    """model_factory.py:63-68."""
+    if cf.architecture == "VGG":
+        return vgg_spec(cf, seed)
+    if cf.architecture == "RESNET":
+        return resnet_spec(cf, seed)
+    raise ValueError("Error: type " + str(cf.architecture) + " is not supported")
+
+
+def synthetic_images(cf, n, seed=0):
+    """uint8 U{0..255} / 255 as float32 NHWC (utils/load_data.py:40)."""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 256, (n, cf.dim, cf.dim, cf.channels), dtype=np.uint8)
+    return (x.astype(F32) / F32(255)).astype(F32)
+
+
+SEED_BASE = 20240607

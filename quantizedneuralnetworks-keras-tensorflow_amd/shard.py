@@ -1,0 +1,60 @@
+"""Data-parallel inference over the GPUs of one node (one process per GPU).
+
+The forward pass is independent per image (BN uses moving statistics, the clips
+are elementwise, weights are replicated), so the batch is cut into contiguous
+equal shards with NO data-path collective; the only exchange is one all-gather
+of the (B/G, classes) float32 logits (RCCL over xGMI on the GPU box, gloo in the
+CPU tests).  40 bytes per image: latency-bound, no bucketing needed.
+
+Not shardable this way: ternary_tanh (global mean|x| over the batch tensor,
+ternary_ops.py:23) -- it needs all-reduced (sum, count) first; see
+`allreduce_mean_abs`.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, rank, world):
+    """Contiguous equal shards; the last ones are padded by the caller if total %
+    world != 0 (ranks must contribute equal-sized tensors to the all-gather)."""
+    per = -(-total // world)
+    lo = min(rank * per, total)
+    hi = min(lo + per, total)
+    return lo, hi, per
+
+
+def shard_batch(x, rank, world):
+    """Return this rank's slice of the global batch, zero-padded to the common size."""
+    lo, hi, per = shard_bounds(x.shape[0], rank, world)
+    part = x[lo:hi]
+    if part.shape[0] < per:
+        pad = torch.zeros((per - part.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        part = torch.cat([part, pad], dim=0)
+    return part.contiguous()
+
+
+def gather_logits(local, total=None, group=None):
+    """All-gather the per-rank logits into (world*per, classes) and drop the padding."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local if total is None else local[:total]
+    world = dist.get_world_size(group)
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                      device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out if total is None else out[:total]
+
+
+def allreduce_mean_abs(x, group=None):
+    """Global mean(|clip(x,-1,1)|) of a batch-sharded tensor (for ternary_tanh)."""
+    s = torch.stack([x.clamp(-1, 1).abs().double().sum(),
+                     torch.tensor(float(x.numel()), dtype=torch.float64, device=x.device)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(s, group=group)
+    return (s[0] / s[1]).float()
+
+
+def sharded_forward(model, x_global, rank, world, group=None):
+    """forward(shard) on every rank + all-gather of the logits."""
+    total = x_global.shape[0]
+    local = model(shard_batch(x_global, rank, world))
+    return gather_logits(local, total, group)

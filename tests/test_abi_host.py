@@ -1,0 +1,117 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol,
+and the Keras-compatible host surface behaves like the reference's classes
+(constructor arguments, build(), weight layouts, get_config, error behaviour).
+No compute call is made here (there is no GPU and no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import qnn_amd
+from qnn_amd import _abi, nets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "qnn_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qnn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared_symbols()
+    assert "qnn_conv2d_forward" in names and "qnn_pack_f32" in names
+    lib = ctypes.CDLL(_abi.lib_path())
+    for n in names:
+        assert hasattr(lib, n), "libqnn_hip.so does not export %s" % n
+    assert sorted(names) == sorted(_abi.EXPORTS)
+    assert _abi.load().qnn_version() == 1
+
+
+def test_no_cpu_fallback():
+    x = torch.zeros(4, 4)
+    with pytest.raises(_abi.QnnError):
+        qnn_amd.binary_tanh(x)
+    with pytest.raises(_abi.QnnError):
+        qnn_amd.quantized_tanh(x, 4)
+    layer = qnn_amd.BinaryConv2D(8, kernel_size=(3, 3), padding="same", device="cpu")
+    with pytest.raises(_abi.QnnError):
+        layer(torch.zeros(1, 4, 4, 3))
+
+
+def test_conv_ctor_surface_and_build():
+    # binary_layers.py:100-158 / quantized_layers.py:104-162
+    l = qnn_amd.BinaryConv2D(64, kernel_size=(3, 3), strides=(1, 1), padding="same",
+                             kernel_initializer="glorot_uniform", kernel_regularizer=None,
+                             input_shape=(32, 32, 3), device="cpu")
+    assert l.H == 1.0 and l.kernel_lr_multiplier == "Glorot" and l.bias_lr_multiplier is None
+    l.build((None, 32, 32, 3))
+    assert tuple(l.kernel.shape) == (3, 3, 3, 64) and tuple(l.bias.shape) == (64,)
+    assert isinstance(l.kernel_lr_multiplier, np.float32)
+    assert l.kernel_lr_multiplier == np.float32(20.0499382)
+    assert float(l.kernel.abs().max()) <= 1.0
+    assert l.lr_multipliers == [l.kernel_lr_multiplier, None]
+    assert l.compute_output_shape((None, 32, 32, 3)) == (None, 32, 32, 64)
+    q = qnn_amd.QuantizedConv2D(16, kernel_size=3, strides=2, padding="same", use_bias=False,
+                                nb=4, H=1, device="cpu")
+    q.build((None, 32, 32, 16))
+    assert q.bias is None and q.lr_multipliers == [q.kernel_lr_multiplier]
+    assert q.compute_output_shape((None, 32, 32, 16)) == (None, 16, 16, 16)
+    cfg = q.get_config()
+    assert cfg["nb"] == 4 and cfg["H"] == 1 and cfg["strides"] == (2, 2)
+    with pytest.raises(ValueError):
+        qnn_amd.BinaryConv2D(8, kernel_size=3, device="cpu").build((None, 8, 8, None))
+
+
+def test_dense_ctor_surface_and_weights_roundtrip():
+    d = qnn_amd.QuantizedDense(10, nb=4, device="cpu")   # units positional (vgg.py:41)
+    d.build((None, 1024))
+    assert tuple(d.kernel.shape) == (1024, 10)
+    assert d.kernel_lr_multiplier == np.float32(1.0 / np.sqrt(1.5 / (1024 + 10)))
+    k = np.random.default_rng(0).uniform(-1, 1, (1024, 10)).astype(np.float32)
+    b = np.arange(10, dtype=np.float32)
+    d.set_weights([k, b])
+    k2, b2 = d.get_weights()
+    np.testing.assert_array_equal(k, k2)
+    np.testing.assert_array_equal(b, b2)
+    with pytest.raises(ValueError):
+        d.set_weights([k])
+    with pytest.raises(ValueError):
+        d.set_weights([k[:10], b])
+    bd = qnn_amd.BinaryDense(10, H="Glorot", device="cpu")
+    bd.build((None, 64))
+    assert bd.H == np.float32(np.sqrt(1.5 / 74))
+    with pytest.raises(AssertionError):
+        qnn_amd.BinaryDense(3, device="cpu").build((5,))
+
+
+def test_aliases():
+    assert qnn_amd.BinaryConvolution2D is qnn_amd.BinaryConv2D
+    assert qnn_amd.QuantizedConvolution2D is qnn_amd.QuantizedConv2D
+
+
+def test_baseline_specs_shapes():
+    macs = {}
+    for idx in range(5):
+        cf = nets.baseline_config(idx)
+        if idx == 4:
+            cf.dim = 32   # same topology, CIFAR-sized, to keep the test light
+        spec = nets.build_spec(cf, nets.SEED_BASE + idx)
+        convs = [op for op in spec if op["op"] == "conv"]
+        dense = [op for op in spec if op["op"] == "dense"]
+        assert len(dense) == 1
+        macs[idx] = len(convs)
+    assert macs == {0: 3, 1: 3, 2: 3, 3: 9, 4: 63}
+    cf = nets.baseline_config(2)
+    spec = nets.build_spec(cf, 1)
+    assert spec[0]["kernel"].shape == (3, 3, 3, 64) and spec[0]["nb"] == 4
+    d = [op for op in spec if op["op"] == "dense"][0]
+    assert d["kernel"].shape == (1024, 10) and d["nb"] == cf.abits   # model_factory.py:31 quirk
+    assert spec[1]["eps"] == 1e-4
+    x = nets.synthetic_images(cf, 3, 7)
+    assert x.shape == (3, 32, 32, 3) and x.dtype == np.float32 and x.max() <= 1.0
+    assert np.array_equal(np.rint(x * 255), x * np.float32(255))

@@ -1,0 +1,422 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Bar: bit-exact for every integer / grid-valued path (XNOR+popcount, packed int4,
+int8, all epilogues); float-input layers are bit-exact against the oracle's
+device-order FMA chain and within 1e-5*max(1,|y|) of the oracle's ideal
+(float64-accumulated) convolution.
+"""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import qnn_amd
+from qnn_amd import _abi, engine, nets
+from oracle import qnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+def edge_values():
+    e = [0.0, -0.0, 2.0 ** -24, 2.0 ** -23, -2.0 ** -24, 1e-9, -1e-9, 1e-45, 0.5, -0.5, 1.0, -1.0,
+         0.0625, 0.1875, 0.3125, 0.4375, 0.9375, 0.96875, -0.0625, -0.1875, -0.3125, -0.9375, -1.2, 1.2,
+         3.5 / 128, 2.5 / 128, 1.5 / 128, 0.5 / 128, -0.5 / 128, 127.5 / 128, 126.5 / 128, 7.5 / 8,
+         6.5 / 8, 1e30, -1e30]
+    return np.array(e, dtype=F32)
+
+
+# ---------------------------------------------------------------------------
+def test_native_library_is_what_runs():
+    assert os.path.exists(_abi.lib_path())
+    assert _abi.load().qnn_version() == 1
+
+
+def test_binary_tanh_matches_oracle():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([edge_values(), rng.standard_normal(100003).astype(F32),
+                        (rng.standard_normal(5000) * 1e-7).astype(F32)])
+    y = host(qnn_amd.binary_tanh(dev(x)))
+    np.testing.assert_array_equal(y, O.binary_tanh(x))
+    np.testing.assert_array_equal(host(qnn_amd.binarize(dev(x))), O.binarize(x))
+
+
+@pytest.mark.parametrize("nb", [2, 3, 4, 8, 16])
+def test_quantized_tanh_matches_oracle(nb):
+    rng = np.random.default_rng(nb)
+    x = np.concatenate([edge_values(), rng.uniform(-1.3, 1.3, 100001).astype(F32),
+                        (np.arange(-300, 300) / 256.0).astype(F32)])
+    y = host(qnn_amd.quantized_tanh(dev(x), nb))
+    np.testing.assert_array_equal(y, O.quantized_tanh(x, nb))
+
+
+def test_ternary_tanh_matches_oracle():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((64, 1000)).astype(F32)
+    np.testing.assert_array_equal(host(qnn_amd.ternary_tanh(dev(x))), O.ternary_tanh(x))
+
+
+@pytest.mark.parametrize("C", [3, 16, 32, 37, 64, 256])
+def test_pack_unpack_roundtrip(C):
+    rng = np.random.default_rng(C)
+    x = rng.standard_normal((5, 7, C)).astype(F32)
+    pixels = 35
+    # binary
+    p = _abi.pack(dev(x), C, _abi.FN_BINARY_TANH, 1, _abi.STORE_BIN)
+    assert p.shape == (pixels, (C + 31) // 32)
+    back = host(_abi.unpack(p, pixels, C, _abi.STORE_BIN, 1)).reshape(x.shape)
+    np.testing.assert_array_equal(back, O.binary_tanh(x))
+    # explicit bit layout: bit j of word w is channel 32w+j
+    words = host(p).view(np.uint32)
+    want = np.zeros_like(words)
+    bits = (O.binary_tanh(x).reshape(pixels, C) > 0)
+    for c in range(C):
+        want[:, c // 32] |= bits[:, c].astype(np.uint32) << np.uint32(c % 32)
+    np.testing.assert_array_equal(words, want)
+    for nb, store in ((2, _abi.STORE_I4), (4, _abi.STORE_I4), (8, _abi.STORE_I8), (5, _abi.STORE_I8)):
+        p = _abi.pack(dev(x), C, _abi.FN_QUANTIZED_TANH, nb, store)
+        back = host(_abi.unpack(p, pixels, C, store, nb)).reshape(x.shape)
+        np.testing.assert_array_equal(back, O.quantized_tanh(x, nb))
+        q = O.quantized_tanh(x, nb)
+        p2 = _abi.pack(dev(q), C, _abi.FN_GRID, nb, store)
+        assert torch.equal(p, p2)
+
+
+def _fixture(code):
+    d = np.load(os.path.join(GOLD, "resnet3_%s.npz" % code))
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    return d, meta
+
+
+@pytest.mark.parametrize("code,nb", [("bb", None), ("44", 4), ("42", 2), ("48", 8)])
+def test_weight_quantizers_on_trained_kernels(code, nb):
+    d, _ = _fixture(code)
+    for key in [k for k in d.files if k.endswith("_kernel")]:
+        k = d[key]
+        if nb is None:
+            w = _abi.Weights(_abi.W_BINARY, 1, 1.0, dev(k), None, 1, True, _abi.STORE_F32)
+            want = O.binarize(k)
+        else:
+            w = _abi.Weights(_abi.W_QUANT, nb, 1.0, dev(k), None, 1, True, _abi.STORE_F32)
+            want = O.quantize(k, nb)
+        got = host(w.dequant()).reshape(want.shape)
+        np.testing.assert_array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------
+# single-layer parity
+# ---------------------------------------------------------------------------
+def _oracle_group(x, op, bn, act, pool, float_conv="ideal"):
+    spec = [dict(op)]
+    if bn is not None:
+        spec.append(bn)
+    if act is not None:
+        spec.append(act)
+    if pool == 2:
+        spec.append({"op": "maxpool", "size": 2})
+    return O.run_spec(spec, x, float_conv=float_conv)
+
+
+def _run_group(x_np, in_act, op, bn, act, pool, out_store):
+    """Drive qnn_conv2d_forward directly.  in_act: None (float32 input) or an act dict
+    describing the grid the input values are on."""
+    N, H, W, C = x_np.shape
+    st = tuple(op.get("strides", (1, 1)))
+    wstore = engine._wstore(op)
+    if in_act is None:
+        x_store, x_bits, xin = _abi.STORE_F32, 0, dev(x_np)
+    else:
+        fn, bits = engine._act_code(in_act)
+        x_store = engine._join_store(bits, wstore)
+        x_bits = bits
+        xin = _abi.pack(dev(x_np), C, _abi.FN_GRID, bits, x_store)
+    w = engine._prepack(op, x_store, torch.device("cuda"), stride=st[0],
+                        same_pad=op.get("padding", "same") == "same")
+    inv = shift = None
+    if bn is not None:
+        i, s = engine.bn_constants(bn)
+        inv, shift = dev(i), dev(s)
+    fn, abits = _abi.FN_NONE, 0
+    if act is not None:
+        fn, abits = engine._act_code(act)
+    y, Ho, Wo = _abi.conv2d(w, xin, x_store, x_bits, N, H, W, inv, shift, fn,
+                            abits if fn == _abi.FN_QUANTIZED_TANH else 0, pool, out_store)
+    kern = _abi.last_kernel()
+    cout = op["kernel"].shape[3]
+    if out_store == _abi.STORE_F32:
+        return host(y), kern
+    out = _abi.unpack(y, N * Ho * Wo, cout, out_store, abits if abits else 1)
+    return host(out).reshape(N, Ho, Wo, cout), kern
+
+
+def _rand_bn(rng, n, var):
+    return dict(op="bn", eps=1e-4, gamma=rng.uniform(-1.5, 1.5, n).astype(F32),
+                beta=(rng.standard_normal(n) * 0.5).astype(F32),
+                mean=(rng.standard_normal(n) * 0.1 * np.sqrt(var)).astype(F32),
+                var=(var * rng.uniform(0.8, 1.25, n)).astype(F32))
+
+
+BIN_ACT = {"op": "act", "fn": "binary_tanh"}
+
+
+def Q(nb):
+    return {"op": "act", "fn": "quantized_tanh", "nb": nb}
+
+
+LAYER_CASES = [
+    # name, (N,H,W,Cin), Cout, k, stride, wkind, wnb, in_act, expected kernel prefix
+    ("bin_64_64", (3, 16, 16, 64), 64, 3, 1, "binary", None, BIN_ACT, "ps_bin_cw2_k3"),
+    ("bin_16_16_pad", (2, 9, 11, 16), 32, 3, 1, "binary", None, BIN_ACT, "ps_bin_cw1_k3"),
+    ("bin_128_64", (2, 8, 8, 128), 64, 3, 1, "binary", None, BIN_ACT, "ps_bin_cw4_k3"),
+    ("bin_256_64", (1, 6, 6, 256), 64, 3, 1, "binary", None, BIN_ACT, "ps_bin_cw8_k3"),
+    ("bin_s2", (2, 16, 16, 32), 64, 3, 2, "binary", None, BIN_ACT, "ps_bin_cw1_k3"),
+    ("bin_1x1_s2", (2, 16, 16, 32), 64, 1, 2, "binary", None, BIN_ACT, "ps_bin_cw1_k1"),
+    ("bin_generic", (2, 8, 8, 96), 40, 3, 1, "binary", None, BIN_ACT, "generic"),
+    ("i4_64_64", (3, 16, 16, 64), 64, 3, 1, "quantized", 4, Q(4), "ps_i4_cw8_k3"),
+    ("i4_16_16", (2, 12, 12, 16), 16, 3, 1, "quantized", 4, Q(4), "ps_i4_cw2_k3"),
+    ("i4_32_64_s2", (2, 16, 16, 32), 64, 3, 2, "quantized", 4, Q(4), "ps_i4_cw4_k3"),
+    ("i4_128_32", (1, 8, 8, 128), 32, 3, 1, "quantized", 4, Q(4), "ps_i4_cw16_k3"),
+    ("i4_1x1_s2", (2, 16, 16, 16), 32, 1, 2, "quantized", 4, Q(4), "ps_i4_cw2_k1"),
+    ("i4_w2_a4", (2, 8, 8, 64), 64, 3, 1, "quantized", 2, Q(4), "ps_i4_cw8_k3"),
+    ("i4_w4_a2", (2, 8, 8, 64), 64, 3, 1, "quantized", 4, Q(2), "ps_i4_cw8_k3"),
+    ("i4_generic_c24", (2, 8, 8, 24), 24, 3, 1, "quantized", 4, Q(4), "generic"),
+    ("i8_32_32", (2, 10, 10, 32), 32, 3, 1, "quantized", 8, Q(8), "ps_i8_cw8_k3"),
+    ("i8_64_64", (1, 8, 8, 64), 64, 3, 1, "quantized", 8, Q(8), "ps_i8_cw16_k3"),
+    ("i8_w4_a8", (1, 8, 8, 16), 16, 3, 1, "quantized", 4, Q(8), "ps_i8_cw4_k3"),
+    ("binw_a4", (2, 8, 8, 64), 64, 3, 1, "binary", None, Q(4), "ps_i4_cw8_k3"),
+    ("w4_abin", (2, 8, 8, 64), 64, 3, 1, "quantized", 4, BIN_ACT, "ps_i4_cw8_k3"),
+]
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+@pytest.mark.parametrize("pool", [1, 2])
+def test_lowbit_conv_layer_bit_exact(case, pool):
+    name, xs, cout, k, stride, wkind, wnb, in_act, kernel_name = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    N, H, W, C = xs
+    pre = rng.standard_normal(xs).astype(F32)
+    x = O.run_spec([in_act], pre)          # values on the input grid
+    op = {"op": "conv", "kind": wkind, "kernel": rng.uniform(-1, 1, (k, k, C, cout)).astype(F32),
+          "bias": (rng.standard_normal(cout) * 0.05).astype(F32), "strides": (stride, stride),
+          "padding": "same"}
+    if wnb:
+        op["nb"] = wnb
+    var = k * k * C * (1.0 if wkind == "binary" else 0.3) * (1.0 if in_act is BIN_ACT else 0.4)
+    bn = _rand_bn(rng, cout, var)
+    Ho = -(-H // stride)
+    Wo = -(-W // stride)
+    if pool == 2 and (Ho < 2 or Wo < 2):
+        pytest.skip("no pool window")
+    # 1) plain float32 output, bias only (the Keras call() surface)
+    got, kern = _run_group(x, in_act, op, None, None, pool, _abi.STORE_F32)
+    assert kern == kernel_name
+    want = _oracle_group(x, op, None, None, pool)
+    np.testing.assert_array_equal(got, want)
+    # 2) fused BN + activation (+pool), packed output, every storage that can hold it
+    for act in (BIN_ACT, Q(2), Q(4), Q(8)):
+        fn, bits = engine._act_code(act)
+        stores = [_abi.STORE_F32]
+        if bits == 1:
+            stores += [_abi.STORE_BIN, _abi.STORE_I4, _abi.STORE_I8]
+        elif bits <= 4:
+            stores += [_abi.STORE_I4, _abi.STORE_I8]
+        else:
+            stores += [_abi.STORE_I8]
+        want = _oracle_group(x, op, bn, act, pool)
+        for out_store in stores:
+            got, _ = _run_group(x, in_act, op, bn, act, pool, out_store)
+            np.testing.assert_array_equal(got, want, err_msg="act=%r store=%d" % (act, out_store))
+    # 3) BN without activation -> float32
+    got, _ = _run_group(x, in_act, op, bn, None, 1, _abi.STORE_F32)
+    np.testing.assert_array_equal(got, _oracle_group(x, op, bn, None, 1))
+
+
+FLOAT_CASES = [
+    ("img3_64", (3, 32, 32, 3), 64, 3, 1, "quantized", 4, "ps_f32_cw3_k3"),
+    ("img3_64_bin", (2, 32, 32, 3), 64, 3, 1, "binary", None, "ps_f32_cw3_k3"),
+    ("img1_64", (2, 28, 28, 1), 64, 3, 1, "binary", None, "ps_f32_cw1_k3"),
+    ("img3_16", (2, 17, 13, 3), 16, 3, 1, "quantized", 8, "ps_f32_cw3_k3"),
+    ("float_generic", (2, 9, 9, 5), 6, 3, 2, "quantized", 4, "generic"),
+]
+
+
+@pytest.mark.parametrize("case", FLOAT_CASES, ids=[c[0] for c in FLOAT_CASES])
+@pytest.mark.parametrize("pool", [1, 2])
+def test_float_input_layer(case, pool):
+    name, xs, cout, k, stride, wkind, wnb, kernel_name = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    N, H, W, C = xs
+    x = (rng.integers(0, 256, xs).astype(F32) / F32(255)).astype(F32)
+    op = {"op": "conv", "kind": wkind, "kernel": rng.uniform(-1, 1, (k, k, C, cout)).astype(F32),
+          "bias": (rng.standard_normal(cout) * 0.05).astype(F32), "strides": (stride, stride),
+          "padding": "same"}
+    if wnb:
+        op["nb"] = wnb
+    got, kern = _run_group(x, None, op, None, None, pool, _abi.STORE_F32)
+    assert kern == kernel_name
+    exact = _oracle_group(x, op, None, None, pool, float_conv="device")
+    np.testing.assert_array_equal(got, exact)           # same FMA chain -> bit-exact
+    ideal = _oracle_group(x, op, None, None, pool)
+    tol = 1e-5 * np.maximum(1.0, np.abs(ideal))          # north_star: 1e-5 on the float path
+    assert np.all(np.abs(got.astype(np.float64) - ideal) <= tol)
+    bn = _rand_bn(rng, cout, k * k * C * 0.3)
+    for act, store in ((BIN_ACT, _abi.STORE_BIN), (Q(4), _abi.STORE_I4), (Q(8), _abi.STORE_I8),
+                       (Q(4), _abi.STORE_F32)):
+        got, _ = _run_group(x, None, op, bn, act, pool, store)
+        want = _oracle_group(x, op, bn, act, pool, float_conv="device")
+        np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("kind,nb,in_act", [("binary", None, BIN_ACT), ("quantized", 4, Q(4)),
+                                            ("quantized", 8, Q(8)), ("quantized", 4, None)])
+def test_dense_layer(kind, nb, in_act):
+    rng = np.random.default_rng(11)
+    N, K, U = 37, 1024, 10
+    pre = rng.standard_normal((N, K)).astype(F32)
+    x = O.run_spec([in_act], pre) if in_act is not None else pre
+    op = {"op": "dense", "kind": kind, "kernel": rng.uniform(-1, 1, (K, U)).astype(F32),
+          "bias": (rng.standard_normal(U) * 0.05).astype(F32)}
+    if nb:
+        op["nb"] = nb
+    cls = qnn_amd.BinaryDense if kind == "binary" else qnn_amd.QuantizedDense
+    layer = cls(U, **({"nb": nb} if nb else {}))
+    layer.build((None, K))
+    layer.set_weights([op["kernel"], op["bias"]])
+    if in_act is not None:
+        layer.input_domain = "binary" if in_act is BIN_ACT else ("quantized", in_act["nb"])
+        got = host(layer(dev(x)))
+        np.testing.assert_array_equal(got, O.run_spec([op], x))
+        # generic float path must agree exactly on grid inputs
+        layer.input_domain = None
+        np.testing.assert_array_equal(host(layer(dev(x))), got)
+    else:
+        got = host(layer(dev(x)))
+        want = O.run_spec([op], x)
+        assert np.all(np.abs(got.astype(np.float64) - want) <= 1e-5 * np.maximum(1, np.abs(want)) * 4)
+
+
+def test_layer_classes_on_trained_weights():
+    """Keras-surface call() on the reference's trained kernels (older topology:
+    use_bias=True), float domain vs packed domain vs oracle."""
+    rng = np.random.default_rng(5)
+    for code, nb, act in (("bb", None, BIN_ACT), ("44", 4, Q(4))):
+        d, meta = _fixture(code)
+        for ci in (2, 8, 10, 16, 17, 21):
+            k, b = d["conv%d_kernel" % ci], d["conv%d_bias" % ci]
+            lm = meta["layers"]["conv%d" % ci]
+            kh, kw, cin, cout = k.shape
+            x = O.run_spec([act], rng.standard_normal((2, 16, 16, cin)).astype(F32))
+            kwargs = dict(kernel_size=(kh, kw), strides=tuple(lm["strides"]), padding=lm["padding"])
+            layer = (qnn_amd.BinaryConv2D(cout, **kwargs) if nb is None
+                     else qnn_amd.QuantizedConv2D(cout, nb=nb, **kwargs))
+            layer.build((None, 16, 16, cin))
+            assert abs(float(layer.kernel_lr_multiplier) - lm["klm"]) < 1e-5
+            layer.set_weights([k, b])
+            op = {"op": "conv", "kind": "binary" if nb is None else "quantized", "kernel": k, "bias": b,
+                  "strides": tuple(lm["strides"]), "padding": lm["padding"]}
+            if nb:
+                op["nb"] = nb
+            want = O.run_spec([op], x)
+            got_float = host(layer(dev(x)))
+            layer.input_domain = "binary" if nb is None else ("quantized", nb)
+            got_packed = host(layer(dev(x)))
+            np.testing.assert_array_equal(got_packed, want)
+            np.testing.assert_array_equal(got_float, want)
+            # faithful replay of the lr-multiplier trick stays within the documented band
+            fa = O.run_spec([dict(op, klm=np.float32(lm["klm"]))], x, mode="faithful")
+            assert np.all(np.abs(fa.astype(np.float64) - want) <= 1e-5 * np.maximum(1, np.abs(want)) * 8)
+
+
+# ---------------------------------------------------------------------------
+# whole networks
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_vgg_configs_end_to_end(idx):
+    cf = nets.baseline_config(idx)
+    spec = nets.build_spec(cf, nets.SEED_BASE + idx)
+    x = nets.synthetic_images(cf, 6, nets.SEED_BASE + idx)
+    want = O.run_spec(spec, x, float_conv="device")
+    fused = engine.FusedModel(spec)
+    got = host(fused(dev(x)))
+    np.testing.assert_array_equal(got, want)
+    graph = host(engine.GraphModel(spec)(dev(x)))
+    np.testing.assert_array_equal(graph, want)
+    layer = host(engine.LayerModel(spec)(dev(x)))
+    np.testing.assert_array_equal(layer, want)
+    ideal = O.run_spec(spec, x)
+    # vs the ideal float conv: identical unless a first-layer value sits within an
+    # ulp of a quantisation threshold (then one code flips); report, do not hide
+    frac = float(np.mean(got != ideal))
+    assert frac <= 0.2, frac
+
+
+def test_vgg_large_8bit_small_batch():
+    cf = nets.baseline_config(3)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 3)
+    x = nets.synthetic_images(cf, 2, nets.SEED_BASE + 3)
+    want = O.run_spec(spec, x, float_conv="device")
+    got = host(engine.FusedModel(spec)(dev(x)))
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("nt,wb,ab", [("full-qnn", 4, 4), ("full-bnn", 1, 1), ("qbnn", 1, 4),
+                                      ("qnn", 4, 4), ("full-qnn", 2, 8)])
+def test_resnet_small(nt, wb, ab):
+    cf = nets.Config(network_type=nt, wbits=wb, abits=ab, architecture="RESNET", nres=1, dim=32)
+    spec = nets.build_spec(cf, 42)
+    x = nets.synthetic_images(cf, 3, 42)
+    want = O.run_spec(spec, x, float_conv="device")
+    got = host(engine.GraphModel(spec)(dev(x)))
+    if nt == "qnn":   # LeakyReLU activations: float convs everywhere -> tolerance
+        np.testing.assert_allclose(got, want, atol=2e-5)
+    else:
+        np.testing.assert_allclose(got, want, atol=1e-6)     # softmax exp differs in the last ulp
+        lm = host(engine.LayerModel(spec)(dev(x)))
+        np.testing.assert_allclose(lm, want, atol=1e-6)
+
+
+def test_mnist_resnet_zero_padding():
+    cf = nets.Config(network_type="full-bnn", architecture="RESNET", dataset="MNIST", dim=28,
+                     channels=1, nres=1)
+    spec = nets.build_spec(cf, 7)
+    x = nets.synthetic_images(cf, 2, 7)
+    want = O.run_spec(spec, x, float_conv="device")
+    got = host(engine.GraphModel(spec)(dev(x)))
+    np.testing.assert_allclose(got, want, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# full-size (batch 4096) size-independent properties
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("idx", [1, 2])
+def test_full_batch_properties(idx):
+    cf = nets.baseline_config(idx)
+    spec = nets.build_spec(cf, nets.SEED_BASE + idx)
+    fused = engine.FusedModel(spec)
+    N = 4096
+    x = dev(nets.synthetic_images(cf, N, 99))
+    y = fused(x)
+    # batch independence: any sub-batch gives the same rows
+    perm = torch.randperm(N, device="cuda")
+    y_perm = fused(x[perm].contiguous())
+    assert torch.equal(y_perm, y[perm])
+    assert torch.equal(fused(x[100:137].contiguous()), y[100:137])
+    # the three engines agree bit for bit at full size
+    assert torch.equal(engine.LayerModel(spec)(x[:512].contiguous()), y[:512])
+    # and the head of the batch equals the oracle
+    want = O.run_spec(spec, host(x[:4]), float_conv="device")
+    np.testing.assert_array_equal(host(y[:4]), want)
+    assert bool(torch.isfinite(y).all())
