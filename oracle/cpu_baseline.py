@@ -89,8 +89,28 @@ def prepare(spec):
     return out
 
 
+def _usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU
+    quota (a GPU box hands each job a share of a much larger host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, int(os.environ.get("QNN_CPU_BASELINE_THREADS", "32"))))
+
+
 def run(cf, spec, seconds=12.0, batch=256):
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     torch.set_num_threads(cores)
     prepared = prepare(spec)
     rng = np.random.default_rng(1)
