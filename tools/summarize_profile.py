@@ -12,9 +12,9 @@ def find(root, suffix):
 
 
 def short(name):
-    name = name.split("(")[0]
     for tok in ("(anonymous namespace)::", "void "):
         name = name.replace(tok, "")
+    name = name.split("(")[0]
     return name[:70]
 
 
