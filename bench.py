@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="replay the forward from a hipGraph")
+    ap.add_argument("--impl", default="auto", choices=["auto", "valu", "mfma"],
+                    help="conv kernel family (results are bit-identical)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,6 +83,7 @@ def main():
 
     pkg = importlib.import_module(PKG)
     nets, engine, shard, abi = pkg.nets, pkg.engine, pkg.shard, pkg._abi
+    abi.set_conv_impl({"auto": 0, "valu": 1, "mfma": 2}[args.impl])
     idx = WORKLOADS[args.workload]
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
@@ -178,7 +181,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": {1: "u1 xnor/popcount", 2: "int4", 3: "int8"}[idx],
             "data": "synthetic",
             "config": {"workload": args.workload, "batch_per_gpu": N, "global_batch": N * world,
-                       "traffic_model": "M1 (packed inter-layer tensors)", "engine": "FusedModel",
+                       "traffic_model": "M1 (packed inter-layer tensors)", "engine": "FusedModel", "conv_impl": args.impl,
                        "hipgraph": graph is not None, "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "kernel": d["kernel"], "layer_index": dom,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

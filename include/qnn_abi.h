@@ -94,6 +94,10 @@ typedef struct qnn_epilogue {
 /* ---- library ------------------------------------------------------------ */
 int         qnn_version(void);
 const char* qnn_last_error(void);
+/* Kernel family for eligible conv layers: 0 = auto (fastest), 1 = VALU kernels only
+ * (XNOR+popcount / v_dot8 / v_dot4), 2 = prefer the int8 MFMA implicit GEMM.
+ * Process-wide; results are bit-identical across families. */
+int         qnn_set_conv_impl(int impl);
 
 /* ---- elementwise activation clips on float32 tensors --------------------- */
 /* binary_ops.binary_tanh, layers/binary_ops.py:37-51 */

@@ -18,7 +18,7 @@ W_FLOAT, W_BINARY, W_QUANT, W_TERNARY = 0, 1, 2, 3
 FN_NONE, FN_BINARY_TANH, FN_QUANTIZED_TANH, FN_TERNARY_TANH, FN_GRID = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "qnn_version", "qnn_last_error", "qnn_last_kernel",
+    "qnn_version", "qnn_last_error", "qnn_last_kernel", "qnn_set_conv_impl",
     "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
     "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32",
     "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant",
@@ -58,6 +58,7 @@ def load():
     lib.qnn_version.restype = ci
     lib.qnn_last_error.restype = ctypes.c_char_p
     lib.qnn_last_kernel.restype = ctypes.c_char_p
+    lib.qnn_set_conv_impl.argtypes = [ci]
     lib.qnn_binary_tanh_f32.argtypes = [vp, vp, sz, vp]
     lib.qnn_quantized_tanh_f32.argtypes = [vp, vp, sz, ci, vp]
     lib.qnn_ternary_tanh_f32.argtypes = [vp, vp, sz, vp, vp]
@@ -81,6 +82,14 @@ def check(rc, what):
     if rc != QNN_OK:
         msg = load().qnn_last_error().decode(errors="replace")
         raise QnnError("%s failed (%d): %s" % (what, rc, msg))
+
+
+IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
+
+
+def set_conv_impl(impl):
+    """0 auto, 1 VALU kernels only, 2 prefer int8 MFMA (bit-identical results)."""
+    check(load().qnn_set_conv_impl(int(impl)), "qnn_set_conv_impl")
 
 
 def last_kernel():

@@ -45,7 +45,16 @@ struct qnn_weights {
     float* d_wq;          // [cout][kh*kw][cin]  quantized values as float32
     float* d_bias;        // [cout] or nullptr
     int32_t* d_corr;      // BIN + same_pad: [64][cout] zero-padding corrections
+    uint8_t* d_mfma;      // int8 image [cout][kh*kw][cin] for the MFMA kernel (may alias d_packed)
+    void* d_mfma_own;     // owned allocation behind d_mfma (I4 store), or nullptr
 };
+
+struct ConvGeom;
+struct EpiArgs;
+int qnn_mfma_prepare_weights(qnn_weights* w, hipStream_t s);
+int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const void* x,
+                        const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len);
+int qnn_conv_impl_pref();
 
 // ---- geometry shared by every conv kernel ------------------------------------
 struct ConvGeom {

@@ -482,7 +482,12 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     char name[64];
     // the pixel-stationary kernel needs whole pool windows (even Ho/Wo are not
     // required: the remainder row/column is simply never produced)
-    if (try_launch_ps(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0) {
+    const int pref = qnn_conv_impl_pref();
+    bool launched = false;
+    if (pref != 1 && !dense)
+        launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
+    if (!launched) launched = try_launch_ps(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
+    if (launched) {
         qnn_set_kernel_name(name);
     } else {
         const size_t total = (size_t)g.N * g.Hp * g.Wp * e.ocw;
@@ -589,6 +594,10 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
         }
     }
     PREPACK_HIP(hipGetLastError());
+    if (qnn_mfma_prepare_weights(w, s) != QNN_OK) {
+        qnn_free_weights(w);
+        return QNN_EHIP;
+    }
 #undef PREPACK_HIP
     *out = w;
     return QNN_OK;
@@ -600,6 +609,7 @@ extern "C" int qnn_free_weights(qnn_weights_t* w) {
     if (w->d_wq) (void)hipFree(w->d_wq);
     if (w->d_bias) (void)hipFree(w->d_bias);
     if (w->d_corr) (void)hipFree(w->d_corr);
+    if (w->d_mfma_own) (void)hipFree(w->d_mfma_own);
     delete w;
     return QNN_OK;
 }

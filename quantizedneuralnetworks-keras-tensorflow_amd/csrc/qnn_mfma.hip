@@ -1,0 +1,346 @@
+// int8 MFMA implicit-GEMM convolution for gfx950 (v_mfma_i32_32x32x32_i8).
+//
+// Replaces the float32 Conv2D that QuantizedConv2D.call emits
+// (layers/quantized_layers.py:171-177) for layers whose activations and weights are
+// stored as int8 codes (wbits/abits <= 8) or packed int4 codes (<= 4 bits): the int4
+// operands are widened to int8 while they are staged into LDS (code*16 in the high
+// nibble of each byte: two VALU ops per 8 codes, no sign-extension needed; the 2^8
+// factor is folded into the power-of-two output scale), so both widths share one
+// MFMA main loop.
+//
+// GEMM view: M = output pixels (N*Ho*Wo), N = cout, K = kh*kw*cin, walked one
+// (tap, 64-channel chunk) per K-step.  A workgroup of WM x WN waves owns a
+// (64*WM) x (64*WN) output tile; every wave a 64x64 sub-tile = 2x2 MFMA tiles, i.e.
+// 4 ds_read_b128 per 4 MFMAs per 32-deep k-step.  A/B tiles are rows of 64 bytes in
+// LDS, 16-byte chunks XOR-swizzled by (row>>2)&3 so that the four 16-lane groups of
+// a ds_read_b128 hit disjoint banks.  Out-of-image taps are staged as zero bytes,
+// which is exactly TF 'SAME' zero padding in the code domain.
+//
+// With max-pooling fused, the M index is ordered "pool window major, 2x2 position
+// minor": rows 4g..4g+3 of the tile are one window and land in four consecutive
+// accumulator registers of ONE lane (C/D layout row = (r&3) + 8*(r>>2) + 4*(lane>>5)),
+// so pooling is an in-lane max -- no cross-lane traffic.
+#include "qnn_common.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+int qnn_conv_impl_pref();   // 0 auto, 1 valu, 2 mfma (qnn_api.hip)
+
+namespace {
+
+struct MfmaGeom {
+    ConvGeom g;
+    int kc;            // 64-channel chunks per tap
+    int steps;         // kh*kw*kc
+    int x_pix_bytes;   // bytes per input pixel as stored
+    long total_q;      // stored output pixels
+};
+
+template <int BITS>
+__device__ __forceinline__ uint32_t pack_lanes(int code) {
+    // OR the BITS-bit codes of (32/BITS) consecutive lanes into one word; the word is
+    // valid in the first lane of each group.  row_shl:n = lane i reads lane i+n.
+    uint32_t x = (uint32_t)code & ((1u << BITS) - 1u);
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, true);
+    x |= t << BITS;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xF, 0xF, true);
+    x |= t << (2 * BITS);
+    if constexpr (BITS == 4) {
+        t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0xF, true);
+        x |= t << 16;
+    }
+    return x;
+}
+
+// XS: QNN_STORE_I8 or QNN_STORE_I4 (storage of x; weights are always int8 bytes here)
+template <int XS, int WM, int WN, int OUT, int POOL>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs e,
+                                                           const uint8_t* __restrict__ x,
+                                                           const uint8_t* __restrict__ wq8,
+                                                           void* __restrict__ y) {
+    constexpr int T = 64 * WM * WN;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int RPP = T / 4;               // rows staged per pass
+    constexpr int NA = BM / RPP, NB = BN / RPP;
+    static_assert(NA >= 1 && NB >= 1, "tile too small for the workgroup");
+    const ConvGeom& g = mg.g;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const lds_a = smem;                          // [2][BM*64]
+    char* const lds_b = smem + 2 * BM * 64;            // [2][BN*64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const long tile = blockIdx.x;
+    const int nbase = blockIdx.y * BN;
+
+    // ---- per-thread staging rows -------------------------------------------------
+    const int srow = tid >> 2, sch = tid & 3;
+    int a_pix0[NA], a_iy0[NA], a_ix0[NA];
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+        const int R = srow + p * RPP;
+        long q;
+        int sub = 0;
+        if constexpr (POOL == 2) { q = tile * (BM / 4) + (R >> 2); sub = R & 3; }
+        else q = tile * BM + R;
+        if (q < mg.total_q) {
+            const int px = (int)(q % g.Wp);
+            const int py = (int)((q / g.Wp) % g.Hp);
+            const int n = (int)(q / ((long)g.Wp * g.Hp));
+            const int oy = py * POOL + (sub >> 1), ox = px * POOL + (sub & 1);
+            a_iy0[p] = oy * g.stride - g.pt;
+            a_ix0[p] = ox * g.stride - g.pl;
+            a_pix0[p] = (n * g.H + a_iy0[p]) * g.W + a_ix0[p];
+        } else {
+            a_iy0[p] = -100000; a_ix0[p] = -100000; a_pix0[p] = 0;   // never in range -> zeros
+        }
+    }
+    const long w_row_bytes = (long)g.kh * g.kw * g.cin;   // int8 bytes per cout
+
+    uint4 ra[NA], rb[NB];
+    auto stage_load = [&](int ks) {
+        const int tap = ks / mg.kc, kc = ks - tap * mg.kc;
+        const int dy = tap / g.kw, dx = tap - dy * g.kw;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int iy = a_iy0[p] + dy, ix = a_ix0[p] + dx;
+            const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const long pix = (long)a_pix0[p] + dy * g.W + dx;
+            if constexpr (XS == QNN_STORE_I8) {
+                const uint8_t* src = x + pix * mg.x_pix_bytes + kc * 64 + sch * 16;
+                ra[p] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+            } else {
+                const uint8_t* src = x + pix * mg.x_pix_bytes + kc * 32 + sch * 8;
+                const uint2 v = ok ? *reinterpret_cast<const uint2*>(src) : make_uint2(0, 0);
+                ra[p] = make_uint4((v.x << 4) & 0xF0F0F0F0u, v.x & 0xF0F0F0F0u,
+                                   (v.y << 4) & 0xF0F0F0F0u, v.y & 0xF0F0F0F0u);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int R = srow + p * RPP;
+            const uint8_t* src = wq8 + (long)(nbase + R) * w_row_bytes + (long)tap * g.cin + kc * 64 + sch * 16;
+            rb[p] = *reinterpret_cast<const uint4*>(src);
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int R = srow + p * RPP;
+            *reinterpret_cast<uint4*>(lds_a + buf * (BM * 64) + R * 64 + ((sch ^ ((R >> 2) & 3)) << 4)) = ra[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int R = srow + p * RPP;
+            *reinterpret_cast<uint4*>(lds_b + buf * (BN * 64) + R * 64 + ((sch ^ ((R >> 2) & 3)) << 4)) = rb[p];
+        }
+    };
+
+    // ---- main loop ----------------------------------------------------------------
+    v16i acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+    const int li = lane & 31, lh = lane >> 5;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    for (int ks = 0; ks < mg.steps; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < mg.steps) stage_load(ks + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v4i fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ra_ = wm * 64 + t * 32 + li;
+                fa[t] = *reinterpret_cast<const v4i*>(lds_a + buf * (BM * 64) + ra_ * 64 +
+                                                      (((kk * 2 + lh) ^ ((ra_ >> 2) & 3)) << 4));
+                const int rb_ = wn * 64 + t * 32 + li;
+                fb[t] = *reinterpret_cast<const v4i*>(lds_b + buf * (BN * 64) + rb_ * 64 +
+                                                      (((kk * 2 + lh) ^ ((rb_ >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (ks + 1 < mg.steps) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------
+    constexpr int OBITS = (OUT == QNN_STORE_BIN) ? 1 : (OUT == QNN_STORE_I4) ? 4 : (OUT == QNN_STORE_I8) ? 8 : 32;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int c = nbase + wn * 64 + b * 32 + li;
+        const float bias = e.bias ? e.bias[c] : 0.0f;
+        const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
+        const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // rows 8*g4 + 4*lh + 0..3 of this 32-row MFMA tile sit in regs 4*g4..4*g4+3
+                float v[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float t = __fmul_rn((float)acc[a][b][4 * g4 + s], e.scale);
+                    t = __fadd_rn(t, bias);
+                    t = __fadd_rn(__fmul_rn(t, inv), shift);
+                    v[s] = t;
+                }
+                const int R0 = wm * 64 + a * 32 + 8 * g4 + 4 * lh;   // tile row of v[0]
+                if constexpr (POOL == 2) {
+                    const long q = tile * (BM / 4) + (R0 >> 2);
+                    const bool live = q < mg.total_q;
+                    if constexpr (OUT == QNN_STORE_F32) {
+                        float r[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            r[s] = v[s];
+                            if (e.fn == QNN_FN_BINARY_TANH) r[s] = qnn_binary_tanh(v[s]);
+                            else if (e.fn == QNN_FN_QUANTIZED_TANH) r[s] = qnn_quantized_tanh(v[s], e.act_m);
+                        }
+                        const float m = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
+                        if (live) ((float*)y)[q * g.cout + c] = m;
+                    } else {
+                        int code = qnn_epi_code(v[0], e);
+#pragma unroll
+                        for (int s = 1; s < 4; ++s) code = max(code, qnn_epi_code(v[s], e));
+                        if constexpr (OUT == QNN_STORE_BIN) {
+                            const unsigned long long m = __ballot(code != 0);
+                            const uint32_t word = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
+                            if (live && li == 0) ((uint32_t*)y)[q * e.ocw + (c >> 5)] = word;
+                        } else {
+                            const uint32_t word = pack_lanes<OBITS>(code);
+                            constexpr int PW = 32 / OBITS;
+                            if (live && (li % PW) == 0) ((uint32_t*)y)[q * e.ocw + c / PW] = word;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const long q = tile * BM + R0 + s;
+                        const bool live = q < mg.total_q;
+                        if constexpr (OUT == QNN_STORE_F32) {
+                            float r = v[s];
+                            if (e.fn == QNN_FN_BINARY_TANH) r = qnn_binary_tanh(r);
+                            else if (e.fn == QNN_FN_QUANTIZED_TANH) r = qnn_quantized_tanh(r, e.act_m);
+                            if (live) ((float*)y)[q * g.cout + c] = r;
+                        } else {
+                            const int code = qnn_epi_code(v[s], e);
+                            if constexpr (OUT == QNN_STORE_BIN) {
+                                const unsigned long long m = __ballot(code != 0);
+                                const uint32_t word = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
+                                if (live && li == 0) ((uint32_t*)y)[q * e.ocw + (c >> 5)] = word;
+                            } else {
+                                const uint32_t word = pack_lanes<OBITS>(code);
+                                constexpr int PW = 32 / OBITS;
+                                if (live && (li % PW) == 0) ((uint32_t*)y)[q * e.ocw + c / PW] = word;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int XS, int WM, int WN, int OUT>
+void launch_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
+                 hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const long rows = mg.total_q * (mg.g.pool == 2 ? 4 : 1);
+    const dim3 grid((unsigned)((rows + BM - 1) / BM), (unsigned)(mg.g.cout / BN));
+    const dim3 block(64 * WM * WN);
+    const size_t lds = 2 * (BM + BN) * 64;
+    if (mg.g.pool == 2)
+        hipLaunchKernelGGL((k_conv_mfma<XS, WM, WN, OUT, 2>), grid, block, lds, s, mg, e,
+                           (const uint8_t*)x, w, y);
+    else
+        hipLaunchKernelGGL((k_conv_mfma<XS, WM, WN, OUT, 1>), grid, block, lds, s, mg, e,
+                           (const uint8_t*)x, w, y);
+}
+
+template <int XS, int WM, int WN>
+int launch_out(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
+               hipStream_t s) {
+    switch (e.out_store) {
+        case QNN_STORE_F32: launch_pool<XS, WM, WN, QNN_STORE_F32>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_BIN: launch_pool<XS, WM, WN, QNN_STORE_BIN>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_I4: launch_pool<XS, WM, WN, QNN_STORE_I4>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_I8: launch_pool<XS, WM, WN, QNN_STORE_I8>(mg, e, x, w, y, s); return 0;
+    }
+    return 1;
+}
+
+// int8 weight image for the I4 path: every packed word (8 nibbles) -> two words of
+// (code*16) bytes in the same even/odd order the activation staging produces
+__global__ __launch_bounds__(256) void k_expand_i4_weights(const uint32_t* __restrict__ packed,
+                                                           uint32_t* __restrict__ out, int words) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) {
+        const uint32_t p = packed[i];
+        out[2 * i] = (p << 4) & 0xF0F0F0F0u;
+        out[2 * i + 1] = p & 0xF0F0F0F0u;
+    }
+}
+
+}  // namespace
+
+// Build the int8 weight image the MFMA kernel reads (called from qnn_prepack_weights).
+int qnn_mfma_prepare_weights(qnn_weights* w, hipStream_t s) {
+    w->d_mfma = nullptr;
+    if (w->cin % 64 != 0 || w->cout % 64 != 0) return QNN_OK;
+    if (w->store == QNN_STORE_I8) {
+        w->d_mfma = (uint8_t*)w->d_packed;      // int8 codes, natural channel order
+        return QNN_OK;
+    }
+    if (w->store != QNN_STORE_I4) return QNN_OK;
+    const int words = w->cout * w->kwords;
+    QNN_HIP(hipMalloc(&w->d_mfma_own, (size_t)words * 8));
+    int grid = (words + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_expand_i4_weights, dim3(grid), dim3(256), 0, s, w->d_packed,
+                       (uint32_t*)w->d_mfma_own, words);
+    w->d_mfma = (uint8_t*)w->d_mfma_own;
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+// returns 0 if launched, 1 if this shape is not eligible
+int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const void* x,
+                        const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len) {
+    if (!w->d_mfma) return 1;
+    if (x_store != QNN_STORE_I8 && x_store != QNN_STORE_I4) return 1;
+    if (g.cin % 64 != 0 || g.cout % 64 != 0) return 1;
+    const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
+    if (g.cout % pw != 0) return 1;
+    MfmaGeom mg;
+    mg.g = g;
+    mg.kc = g.cin / 64;
+    mg.steps = g.kh * g.kw * mg.kc;
+    mg.x_pix_bytes = x_store == QNN_STORE_I8 ? g.cin : g.cin / 2;
+    mg.total_q = (long)g.N * g.Hp * g.Wp;
+    EpiArgs e2 = e;
+    if (x_store == QNN_STORE_I4) e2.scale = e.scale * (1.0f / 256.0f);   // both operands carry *16
+    const bool wide = (g.cout % 128) == 0;
+    snprintf(name, name_len, "mfma_%s_%s", x_store == QNN_STORE_I8 ? "i8" : "i4", wide ? "128x128" : "256x64");
+    int rc;
+    if (x_store == QNN_STORE_I8)
+        rc = wide ? launch_out<QNN_STORE_I8, 2, 2>(mg, e2, x, w->d_mfma, y, s)
+                  : launch_out<QNN_STORE_I8, 4, 1>(mg, e2, x, w->d_mfma, y, s);
+    else
+        rc = wide ? launch_out<QNN_STORE_I4, 2, 2>(mg, e2, x, w->d_mfma, y, s)
+                  : launch_out<QNN_STORE_I4, 4, 1>(mg, e2, x, w->d_mfma, y, s);
+    return rc;
+}

@@ -198,13 +198,38 @@ LAYER_CASES = [
     ("i8_w4_a8", (1, 8, 8, 16), 16, 3, 1, "quantized", 4, Q(8), "ps_i8_cw4_k3"),
     ("binw_a4", (2, 8, 8, 64), 64, 3, 1, "binary", None, Q(4), "ps_i4_cw8_k3"),
     ("w4_abin", (2, 8, 8, 64), 64, 3, 1, "quantized", 4, BIN_ACT, "ps_i4_cw8_k3"),
+    # shapes aimed at the int8-MFMA implicit GEMM (cin, cout multiples of 64)
+    ("i8_256_256", (2, 8, 8, 256), 256, 3, 1, "quantized", 8, Q(8), "generic"),
+    ("i8_64_128", (3, 10, 6, 64), 128, 3, 1, "quantized", 8, Q(8), "ps_i8_cw16_k3"),
+    ("i4_128_128", (2, 12, 12, 128), 128, 3, 1, "quantized", 4, Q(4), "ps_i4_cw16_k3"),
+    ("i4_64_64_s2", (2, 14, 14, 64), 64, 3, 2, "quantized", 4, Q(4), "ps_i4_cw8_k3"),
+    ("i8_128_64_1x1_s2", (2, 12, 12, 128), 64, 1, 2, "quantized", 8, Q(8), "generic"),
+    ("i4_64_64_big", (37, 16, 16, 64), 64, 3, 1, "quantized", 4, Q(4), "ps_i4_cw8_k3"),
 ]
+
+
+def _mfma_eligible(case):
+    name, xs, cout, k, stride, wkind, wnb, in_act, _ = case
+    if in_act is BIN_ACT and wkind == "binary":
+        return False
+    return xs[3] % 64 == 0 and cout % 64 == 0
+
+
+@pytest.fixture(params=[_abi.IMPL_VALU, _abi.IMPL_MFMA], ids=["valu", "mfma"])
+def impl(request):
+    _abi.set_conv_impl(request.param)
+    yield request.param
+    _abi.set_conv_impl(_abi.IMPL_AUTO)
 
 
 @pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
 @pytest.mark.parametrize("pool", [1, 2])
-def test_lowbit_conv_layer_bit_exact(case, pool):
+def test_lowbit_conv_layer_bit_exact(case, pool, impl):
     name, xs, cout, k, stride, wkind, wnb, in_act, kernel_name = case
+    if impl == _abi.IMPL_MFMA:
+        if not _mfma_eligible(case):
+            pytest.skip("shape not eligible for the MFMA kernel")
+        kernel_name = "mfma_"
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     N, H, W, C = xs
     pre = rng.standard_normal(xs).astype(F32)
@@ -222,7 +247,7 @@ def test_lowbit_conv_layer_bit_exact(case, pool):
         pytest.skip("no pool window")
     # 1) plain float32 output, bias only (the Keras call() surface)
     got, kern = _run_group(x, in_act, op, None, None, pool, _abi.STORE_F32)
-    assert kern == kernel_name
+    assert kern.startswith(kernel_name), kern
     want = _oracle_group(x, op, None, None, pool)
     np.testing.assert_array_equal(got, want)
     # 2) fused BN + activation (+pool), packed output, every storage that can hold it
@@ -344,7 +369,7 @@ def test_layer_classes_on_trained_weights():
 # whole networks
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("idx", [0, 1, 2])
-def test_vgg_configs_end_to_end(idx):
+def test_vgg_configs_end_to_end(idx, impl):
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     x = nets.synthetic_images(cf, 6, nets.SEED_BASE + idx)
@@ -363,7 +388,7 @@ def test_vgg_configs_end_to_end(idx):
     assert frac <= 0.2, frac
 
 
-def test_vgg_large_8bit_small_batch():
+def test_vgg_large_8bit_small_batch(impl):
     cf = nets.baseline_config(3)
     spec = nets.build_spec(cf, nets.SEED_BASE + 3)
     x = nets.synthetic_images(cf, 2, nets.SEED_BASE + 3)
@@ -402,7 +427,7 @@ def test_mnist_resnet_zero_padding():
 # full-size (batch 4096) size-independent properties
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("idx", [1, 2])
-def test_full_batch_properties(idx):
+def test_full_batch_properties(idx, impl):
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     fused = engine.FusedModel(spec)
