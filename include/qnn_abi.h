@@ -105,8 +105,8 @@ int qnn_binary_tanh_f32(const float* x, float* y, size_t n, void* stream);
 /* quantized_ops.quantized_tanh (and quantize), layers/quantized_ops.py:49-66,87-100 */
 int qnn_quantized_tanh_f32(const float* x, float* y, size_t n, int nb, void* stream);
 /* ternary_ops.ternary_tanh, layers/ternary_ops.py:52-54.  Needs the global
- * mean(|clip(x)|) first: workspace = 2 doubles... provided by caller (16 bytes,
- * device memory).  Two kernels on `stream`. */
+ * mean(|clip(x)|) first: `workspace16` is 16 bytes of caller-owned device memory
+ * for the running sum.  Memset + two kernels on `stream`. */
 int qnn_ternary_tanh_f32(const float* x, float* y, size_t n, void* workspace16, void* stream);
 
 /* ---- pack / unpack between float32 NHWC and packed storage --------------- */
