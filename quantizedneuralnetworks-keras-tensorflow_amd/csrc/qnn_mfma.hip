@@ -53,6 +53,71 @@ __device__ __forceinline__ uint32_t pack_lanes(int code) {
     return x;
 }
 
+// Epilogue of four consecutive accumulator rows of one lane (one output channel c).
+// v[0..3]: conv results (scaled).  POOL==2: the four rows are one 2x2 pool window
+// (stored pixel q0); POOL==1: four consecutive stored pixels q0..q0+3.
+template <int OUT, int POOL>
+__device__ __forceinline__ void emit_group(float (&v)[4], float bias, float inv, float shift,
+                                           const EpiArgs& e, int c, int li, int lh, long q0,
+                                           long total_q, int cout, void* __restrict__ y) {
+    constexpr int OBITS = (OUT == QNN_STORE_BIN) ? 1 : (OUT == QNN_STORE_I4) ? 4 : (OUT == QNN_STORE_I8) ? 8 : 32;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float t = __fadd_rn(v[s], bias);
+        v[s] = __fadd_rn(__fmul_rn(t, inv), shift);
+    }
+    if constexpr (POOL == 2) {
+        const bool live = q0 < total_q;
+        if constexpr (OUT == QNN_STORE_F32) {
+            float r[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                r[s] = v[s];
+                if (e.fn == QNN_FN_BINARY_TANH) r[s] = qnn_binary_tanh(v[s]);
+                else if (e.fn == QNN_FN_QUANTIZED_TANH) r[s] = qnn_quantized_tanh(v[s], e.act_m);
+            }
+            const float m = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
+            if (live) ((float*)y)[q0 * cout + c] = m;
+        } else {
+            // the clip is monotone: clip(max(v)) == max(clip(v)) exactly
+            const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            const int code = qnn_epi_code(vm, e);
+            if constexpr (OUT == QNN_STORE_BIN) {
+                const unsigned long long m = __ballot(code != 0);
+                const uint32_t word = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
+                if (live && li == 0) ((uint32_t*)y)[q0 * e.ocw + (c >> 5)] = word;
+            } else {
+                const uint32_t word = pack_lanes<OBITS>(code);
+                constexpr int PW = 32 / OBITS;
+                if (live && (li % PW) == 0) ((uint32_t*)y)[q0 * e.ocw + c / PW] = word;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long q = q0 + s;
+            const bool live = q < total_q;
+            if constexpr (OUT == QNN_STORE_F32) {
+                float r = v[s];
+                if (e.fn == QNN_FN_BINARY_TANH) r = qnn_binary_tanh(r);
+                else if (e.fn == QNN_FN_QUANTIZED_TANH) r = qnn_quantized_tanh(r, e.act_m);
+                if (live) ((float*)y)[q * cout + c] = r;
+            } else {
+                const int code = qnn_epi_code(v[s], e);
+                if constexpr (OUT == QNN_STORE_BIN) {
+                    const unsigned long long m = __ballot(code != 0);
+                    const uint32_t word = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
+                    if (live && li == 0) ((uint32_t*)y)[q * e.ocw + (c >> 5)] = word;
+                } else {
+                    const uint32_t word = pack_lanes<OBITS>(code);
+                    constexpr int PW = 32 / OBITS;
+                    if (live && (li % PW) == 0) ((uint32_t*)y)[q * e.ocw + c / PW] = word;
+                }
+            }
+        }
+    }
+}
+
 // XS: QNN_STORE_I8 or QNN_STORE_I4 (storage of x; weights are always int8 bytes here)
 template <int XS, int WM, int WN, int OUT, int POOL>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs e,
@@ -179,7 +244,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
     }
 
     // ---- epilogue -------------------------------------------------------------------
-    constexpr int OBITS = (OUT == QNN_STORE_BIN) ? 1 : (OUT == QNN_STORE_I4) ? 4 : (OUT == QNN_STORE_I8) ? 8 : 32;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int c = nbase + wn * 64 + b * 32 + li;
@@ -193,64 +257,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
                 // rows 8*g4 + 4*lh + 0..3 of this 32-row MFMA tile sit in regs 4*g4..4*g4+3
                 float v[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float t = __fmul_rn((float)acc[a][b][4 * g4 + s], e.scale);
-                    t = __fadd_rn(t, bias);
-                    t = __fadd_rn(__fmul_rn(t, inv), shift);
-                    v[s] = t;
-                }
+                for (int s = 0; s < 4; ++s) v[s] = __fmul_rn((float)acc[a][b][4 * g4 + s], e.scale);
                 const int R0 = wm * 64 + a * 32 + 8 * g4 + 4 * lh;   // tile row of v[0]
-                if constexpr (POOL == 2) {
-                    const long q = tile * (BM / 4) + (R0 >> 2);
-                    const bool live = q < mg.total_q;
-                    if constexpr (OUT == QNN_STORE_F32) {
-                        float r[4];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            r[s] = v[s];
-                            if (e.fn == QNN_FN_BINARY_TANH) r[s] = qnn_binary_tanh(v[s]);
-                            else if (e.fn == QNN_FN_QUANTIZED_TANH) r[s] = qnn_quantized_tanh(v[s], e.act_m);
-                        }
-                        const float m = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
-                        if (live) ((float*)y)[q * g.cout + c] = m;
-                    } else {
-                        int code = qnn_epi_code(v[0], e);
-#pragma unroll
-                        for (int s = 1; s < 4; ++s) code = max(code, qnn_epi_code(v[s], e));
-                        if constexpr (OUT == QNN_STORE_BIN) {
-                            const unsigned long long m = __ballot(code != 0);
-                            const uint32_t word = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
-                            if (live && li == 0) ((uint32_t*)y)[q * e.ocw + (c >> 5)] = word;
-                        } else {
-                            const uint32_t word = pack_lanes<OBITS>(code);
-                            constexpr int PW = 32 / OBITS;
-                            if (live && (li % PW) == 0) ((uint32_t*)y)[q * e.ocw + c / PW] = word;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const long q = tile * BM + R0 + s;
-                        const bool live = q < mg.total_q;
-                        if constexpr (OUT == QNN_STORE_F32) {
-                            float r = v[s];
-                            if (e.fn == QNN_FN_BINARY_TANH) r = qnn_binary_tanh(r);
-                            else if (e.fn == QNN_FN_QUANTIZED_TANH) r = qnn_quantized_tanh(r, e.act_m);
-                            if (live) ((float*)y)[q * g.cout + c] = r;
-                        } else {
-                            const int code = qnn_epi_code(v[s], e);
-                            if constexpr (OUT == QNN_STORE_BIN) {
-                                const unsigned long long m = __ballot(code != 0);
-                                const uint32_t word = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
-                                if (live && li == 0) ((uint32_t*)y)[q * e.ocw + (c >> 5)] = word;
-                            } else {
-                                const uint32_t word = pack_lanes<OBITS>(code);
-                                constexpr int PW = 32 / OBITS;
-                                if (live && (li % PW) == 0) ((uint32_t*)y)[q * e.ocw + c / PW] = word;
-                            }
-                        }
-                    }
-                }
+                const long q0 = (POOL == 2) ? tile * (BM / 4) + (R0 >> 2) : tile * BM + R0;
+                emit_group<OUT, POOL>(v, bias, inv, shift, e, c, li, lh, q0, mg.total_q, g.cout, y);
             }
         }
     }
@@ -281,6 +291,131 @@ int launch_out(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_
         case QNN_STORE_I4: launch_pool<XS, WM, WN, QNN_STORE_I4>(mg, e, x, w, y, s); return 0;
         case QNN_STORE_I8: launch_pool<XS, WM, WN, QNN_STORE_I8>(mg, e, x, w, y, s); return 0;
     }
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------
+// Float-input first layer on the float32 matrix pipe (v_mfma_f32_32x32x2_f32).
+// gfx950's f32 MFMA is bit-for-bit a k-ordered fmaf chain (one rounding per product,
+// no wider accumulation), i.e. exactly the (dy,dx,c)-ordered chain the VALU kernel
+// and the oracle's conv2d_device_order evaluate -- but it runs beside the VALU, which
+// is left to the epilogue.  M = pixels (32 per tile), N = cout (32 per MFMA tile),
+// K = 9*CIN padded to even.  Each wave keeps ALL its filters in VGPRs and walks the
+// pixel tiles; no LDS, no barriers.
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <int CIN, int NT, int OUT, int POOL>   // NT = cout / 32
+__global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
+                                                         const float* __restrict__ x,
+                                                         const float* __restrict__ wq,
+                                                         void* __restrict__ y, long total_q,
+                                                         long tiles) {
+    constexpr int K = 9 * CIN;
+    constexpr int KS = (K + 1) / 2;          // MFMA k-steps of 2
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+
+    // B operand: lane (li, lh) holds w[k = 2s+lh][cout = nt*32 + li]
+    float wb[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 2 * s + lh;
+            wb[nt][s] = k < K ? wq[(long)(nt * 32 + li) * K + k] : 0.0f;
+        }
+    float bias[NT], inv[NT], shift[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = nt * 32 + li;
+        bias[nt] = e.bias ? e.bias[c] : 0.0f;
+        inv[nt] = e.bn_inv ? e.bn_inv[c] : 1.0f;
+        shift[nt] = e.bn_inv ? e.bn_shift[c] : 0.0f;
+    }
+
+    for (long tile = wave_id; tile < tiles; tile += nwaves) {
+        // ---- this lane's pixel (row li of the tile) ----
+        long q;
+        int sub = 0;
+        if constexpr (POOL == 2) { q = tile * 8 + (li >> 2); sub = li & 3; }
+        else q = tile * 32 + li;
+        const bool rowlive = q < total_q;
+        const long qq = rowlive ? q : total_q - 1;
+        const int px = (int)(qq % g.Wp);
+        const int py = (int)((qq / g.Wp) % g.Hp);
+        const int n = (int)(qq / ((long)g.Wp * g.Hp));
+        const int oy = py * POOL + (sub >> 1), ox = px * POOL + (sub & 1);
+        float vals[K + 1];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * g.stride + dy - g.pt;
+            const bool rin = (unsigned)iy < (unsigned)g.H;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * g.stride + dx - g.pl;
+                const bool inb = rin && (unsigned)ix < (unsigned)g.W;
+                const float* p = x + (((long)n * g.H + (inb ? iy : 0)) * g.W + (inb ? ix : 0)) * CIN;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) vals[(dy * 3 + dx) * CIN + c] = inb ? p[c] : 0.0f;
+            }
+        }
+        vals[K] = 0.0f;
+        // ---- K-ordered MFMA chain ----
+        v16f acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float a = lh ? vals[(2 * s + 1 <= K) ? 2 * s + 1 : K] : vals[2 * s];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[nt][s], acc[nt], 0, 0, 0);
+        }
+        // ---- epilogue ----
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = nt * 32 + li;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float v[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[s] = acc[nt][4 * g4 + s];
+                const int R0 = 8 * g4 + 4 * lh;
+                const long q0 = (POOL == 2) ? tile * 8 + (R0 >> 2) : tile * 32 + R0;
+                emit_group<OUT, POOL>(v, bias[nt], inv[nt], shift[nt], e, c, li, lh, q0, total_q, g.cout, y);
+            }
+        }
+    }
+}
+
+template <int CIN, int NT>
+int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float* wq, void* y,
+                 hipStream_t s) {
+    const long total_q = (long)g.N * g.Hp * g.Wp;
+    const long rows = total_q * (g.pool == 2 ? 4 : 1);
+    const long tiles = (rows + 31) / 32;
+    long blocks = (tiles + 3) / 4;
+    const long max_blocks = 256 * 4;            // persistent: 4 blocks (16 waves) per CU
+    if (blocks > max_blocks) blocks = max_blocks;
+    const dim3 grid((unsigned)blocks), block(256);
+    const float* xf = (const float*)x;
+#define FIRST_CASE(OUT)                                                                      \
+    if (e.out_store == OUT) {                                                                \
+        if (g.pool == 2)                                                                     \
+            hipLaunchKernelGGL((k_conv_first_mfma<CIN, NT, OUT, 2>), grid, block, 0, s, g, e, xf, wq, y, total_q, tiles); \
+        else                                                                                 \
+            hipLaunchKernelGGL((k_conv_first_mfma<CIN, NT, OUT, 1>), grid, block, 0, s, g, e, xf, wq, y, total_q, tiles); \
+        return 0;                                                                            \
+    }
+    FIRST_CASE(QNN_STORE_F32)
+    FIRST_CASE(QNN_STORE_BIN)
+    FIRST_CASE(QNN_STORE_I4)
+    FIRST_CASE(QNN_STORE_I8)
+#undef FIRST_CASE
     return 1;
 }
 
@@ -320,6 +455,15 @@ int qnn_mfma_prepare_weights(qnn_weights* w, hipStream_t s) {
 // returns 0 if launched, 1 if this shape is not eligible
 int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const void* x,
                         const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len) {
+    if (x_store == QNN_STORE_F32) {
+        // float-input first layer on the f32 matrix pipe
+        if (g.kh != 3 || g.kw != 3 || (g.cin != 1 && g.cin != 3) || g.cout != 64) return 1;
+        const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
+        if (g.cout % pw != 0) return 1;
+        snprintf(name, name_len, "mfma_f32_first_cin%d", g.cin);
+        return g.cin == 3 ? launch_first<3, 2>(g, e, x, w->d_wq, y, s)
+                          : launch_first<1, 2>(g, e, x, w->d_wq, y, s);
+    }
     if (!w->d_mfma) return 1;
     if (x_store != QNN_STORE_I8 && x_store != QNN_STORE_I4) return 1;
     if (g.cin % 64 != 0 || g.cout % 64 != 0) return 1;
