@@ -56,6 +56,28 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                         const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len);
 int qnn_conv_impl_pref();
 
+// ---- division by a launch-constant via multiply-high (dividends < 2^31) ----------
+struct FastDiv {
+    uint32_t d, m;
+    int s;
+};
+static inline FastDiv qnn_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d; f.m = 0; f.s = 0;
+    if (d > 1) {
+        int s = 0;
+        while ((1ull << s) < d) ++s;
+        f.s = s;
+        f.m = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
+    }
+    return f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t qnn_div(uint32_t q, const FastDiv& f) {
+    return f.d == 1 ? q : (__umulhi(q, f.m) >> (f.s - 1));
+}
+#endif
+
 // ---- geometry shared by every conv kernel ------------------------------------
 struct ConvGeom {
     int N, H, W, Ho, Wo;       // Ho/Wo: conv output (before pooling)
@@ -64,6 +86,7 @@ struct ConvGeom {
     int cw, kwords;
     int pool;                  // 1 or 2
     int Hp, Wp;                // stored output size (Ho/pool, Wo/pool)
+    FastDiv fd_wp, fd_hp;      // q -> (n, py, px) without integer division
 };
 
 struct EpiArgs {

@@ -235,15 +235,16 @@ __global__ __launch_bounds__(kBlock) void k_conv_ps(ConvGeom g, EpiArgs e,
     constexpr int OBITS = (OUT == QNN_STORE_F32) ? 32 : 32 / PWO;
 
     // ---- lane -> conv pixel (pool windows occupy aligned lane quads) ----
-    const long gl = (long)blockIdx.x * kBlock + threadIdx.x;
-    const long total_q = (long)g.N * g.Hp * g.Wp;
-    const long q0 = (g.pool == 2) ? (gl >> 2) : gl;
+    const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t total_q = (uint32_t)g.N * g.Hp * g.Wp;
+    const uint32_t q0 = (g.pool == 2) ? (gl >> 2) : gl;
     const int sub = (g.pool == 2) ? (int)(gl & 3) : 0;
     const bool live = q0 < total_q;
-    const long q = live ? q0 : total_q - 1;
-    const int px = (int)(q % g.Wp);
-    const int py = (int)((q / g.Wp) % g.Hp);
-    const int n = (int)(q / ((long)g.Wp * g.Hp));
+    const uint32_t q = live ? q0 : total_q - 1;
+    const uint32_t qrow = qnn_div(q, g.fd_wp);
+    const int px = (int)(q - qrow * g.Wp);
+    const int n = (int)qnn_div(qrow, g.fd_hp);
+    const int py = (int)(qrow - (uint32_t)n * g.Hp);
     const int oy = py * g.pool + (sub >> 1);
     const int ox = px * g.pool + (sub & 1);
 
@@ -327,10 +328,10 @@ __global__ __launch_bounds__(kBlock) void k_conv_ps(ConvGeom g, EpiArgs e,
         }
         if (live && sub == 0) {
             if constexpr (OUT == QNN_STORE_F32)
-                *reinterpret_cast<float4*>((float*)y + q * g.cout + c0) =
+                *reinterpret_cast<float4*>((float*)y + (long)q * g.cout + c0) =
                     make_float4(fv[0], fv[1], fv[2], fv[3]);
             else
-                ((uint32_t*)y)[q * e.ocw + c0 / PWO] = word;
+                ((uint32_t*)y)[(long)q * e.ocw + c0 / PWO] = word;
         }
     }
 }
@@ -472,6 +473,10 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     QNN_REQUIRE(!dense || g.pool == 1, QNN_EINVAL, "dense_forward: pool must be 1");
     g.Hp = g.Ho / g.pool; g.Wp = g.Wo / g.pool;   // MaxPooling2D 'valid' drops the remainder
     QNN_REQUIRE(g.Hp > 0 && g.Wp > 0, QNN_EINVAL, "conv_forward: pooled output is empty");
+    QNN_REQUIRE((double)g.N * g.Ho * g.Wo < 2.0e9 && (double)g.N * g.H * g.W * (g.cw > g.cin ? g.cw : g.cin) < 9.0e18,
+                QNN_EUNSUPPORTED, "conv_forward: more than 2^31 output pixels in one call");
+    g.fd_wp = qnn_fastdiv((uint32_t)g.Wp);
+    g.fd_hp = qnn_fastdiv((uint32_t)g.Hp);
     EpiArgs e;
     int rc = check_epilogue(w, epi, xshift, &e);
     if (rc != QNN_OK) return rc;

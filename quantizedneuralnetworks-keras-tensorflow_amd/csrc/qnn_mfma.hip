@@ -153,9 +153,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
         if constexpr (POOL == 2) { q = tile * (BM / 4) + (R >> 2); sub = R & 3; }
         else q = tile * BM + R;
         if (q < mg.total_q) {
-            const int px = (int)(q % g.Wp);
-            const int py = (int)((q / g.Wp) % g.Hp);
-            const int n = (int)(q / ((long)g.Wp * g.Hp));
+            const uint32_t qrow = qnn_div((uint32_t)q, g.fd_wp);
+            const int px = (int)((uint32_t)q - qrow * g.Wp);
+            const int n = (int)qnn_div(qrow, g.fd_hp);
+            const int py = (int)(qrow - (uint32_t)n * g.Hp);
             const int oy = py * POOL + (sub >> 1), ox = px * POOL + (sub & 1);
             a_iy0[p] = oy * g.stride - g.pt;
             a_ix0[p] = ox * g.stride - g.pl;
@@ -342,10 +343,11 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
         if constexpr (POOL == 2) { q = tile * 8 + (li >> 2); sub = li & 3; }
         else q = tile * 32 + li;
         const bool rowlive = q < total_q;
-        const long qq = rowlive ? q : total_q - 1;
-        const int px = (int)(qq % g.Wp);
-        const int py = (int)((qq / g.Wp) % g.Hp);
-        const int n = (int)(qq / ((long)g.Wp * g.Hp));
+        const uint32_t qq = (uint32_t)(rowlive ? q : total_q - 1);
+        const uint32_t qrow = qnn_div(qq, g.fd_wp);
+        const int px = (int)(qq - qrow * g.Wp);
+        const int n = (int)qnn_div(qrow, g.fd_hp);
+        const int py = (int)(qrow - (uint32_t)n * g.Hp);
         const int oy = py * POOL + (sub >> 1), ox = px * POOL + (sub & 1);
         float vals[K + 1];
 #pragma unroll
