@@ -336,34 +336,47 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
         shift[nt] = e.bn_inv ? e.bn_shift[c] : 0.0f;
     }
 
-    for (long tile = wave_id; tile < tiles; tile += nwaves) {
-        // ---- this lane's pixel (row li of the tile) ----
+    // A operand of tile `t`: lane (li, lh) supplies x[pixel li][k = 2s+lh]; only the
+    // address offset differs between the two lane halves, and both candidates are
+    // wave-uniform, so the gather is KS predicated dword loads per lane.
+    auto load_tile = [&](long t, float (&av)[KS]) {
         long q;
         int sub = 0;
-        if constexpr (POOL == 2) { q = tile * 8 + (li >> 2); sub = li & 3; }
-        else q = tile * 32 + li;
-        const bool rowlive = q < total_q;
-        const uint32_t qq = (uint32_t)(rowlive ? q : total_q - 1);
+        if constexpr (POOL == 2) { q = t * 8 + (li >> 2); sub = li & 3; }
+        else q = t * 32 + li;
+        const uint32_t qq = (uint32_t)(q < total_q ? q : total_q - 1);
         const uint32_t qrow = qnn_div(qq, g.fd_wp);
         const int px = (int)(qq - qrow * g.Wp);
         const int n = (int)qnn_div(qrow, g.fd_hp);
         const int py = (int)(qrow - (uint32_t)n * g.Hp);
-        const int oy = py * POOL + (sub >> 1), ox = px * POOL + (sub & 1);
-        float vals[K + 1];
+        const int iy0 = (py * POOL + (sub >> 1)) * g.stride - g.pt;
+        const int ix0 = (px * POOL + (sub & 1)) * g.stride - g.pl;
+        bool inb[9];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int iy = oy * g.stride + dy - g.pt;
-            const bool rin = (unsigned)iy < (unsigned)g.H;
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ix = ox * g.stride + dx - g.pl;
-                const bool inb = rin && (unsigned)ix < (unsigned)g.W;
-                const float* p = x + (((long)n * g.H + (inb ? iy : 0)) * g.W + (inb ? ix : 0)) * CIN;
+            for (int dx = 0; dx < 3; ++dx)
+                inb[dy * 3 + dx] = (unsigned)(iy0 + dy) < (unsigned)g.H && (unsigned)(ix0 + dx) < (unsigned)g.W;
+        const long base = (((long)n * g.H + iy0) * g.W + ix0) * CIN;
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) vals[(dy * 3 + dx) * CIN + c] = inb ? p[c] : 0.0f;
-            }
+        for (int s = 0; s < KS; ++s) {
+            constexpr int dummy = 0; (void)dummy;
+            const int ke = 2 * s, ko = 2 * s + 1;
+            const int te = ke / CIN, ce = ke % CIN;
+            const int to = (ko < K) ? ko / CIN : 0, co = (ko < K) ? ko % CIN : 0;
+            const int off_e = ((te / 3) * g.W + (te % 3)) * CIN + ce;
+            const int off_o = ((to / 3) * g.W + (to % 3)) * CIN + co;
+            const bool ok = lh ? (ko < K && inb[to]) : inb[te];
+            const int off = lh ? off_o : off_e;
+            av[s] = ok ? x[base + off] : 0.0f;
         }
-        vals[K] = 0.0f;
+    };
+
+    float cur[KS], nxt[KS];
+    if (wave_id < tiles) load_tile(wave_id, cur);
+    for (long tile = wave_id; tile < tiles; tile += nwaves) {
+        const bool more = tile + nwaves < tiles;
+        if (more) load_tile(tile + nwaves, nxt);
         // ---- K-ordered MFMA chain ----
         v16f acc[NT];
 #pragma unroll
@@ -372,10 +385,9 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const float a = lh ? vals[(2 * s + 1 <= K) ? 2 * s + 1 : K] : vals[2 * s];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[nt][s], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], wb[nt][s], acc[nt], 0, 0, 0);
         }
         // ---- epilogue ----
 #pragma unroll
@@ -390,6 +402,10 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
                 const long q0 = (POOL == 2) ? tile * 8 + (R0 >> 2) : tile * 32 + R0;
                 emit_group<OUT, POOL>(v, bias[nt], inv[nt], shift[nt], e, c, li, lh, q0, total_q, g.cout, y);
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
         }
     }
 }
