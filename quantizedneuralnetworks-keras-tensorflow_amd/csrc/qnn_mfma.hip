@@ -37,83 +37,152 @@ struct MfmaGeom {
     long total_q;      // stored output pixels
 };
 
-template <int BITS>
-__device__ __forceinline__ uint32_t pack_lanes(int code) {
-    // OR the BITS-bit codes of (32/BITS) consecutive lanes into one word; the word is
-    // valid in the first lane of each group.  row_shl:n = lane i reads lane i+n.
-    uint32_t x = (uint32_t)code & ((1u << BITS) - 1u);
-    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, true);
-    x |= t << BITS;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x102, 0xF, 0xF, true);
-    x |= t << (2 * BITS);
-    if constexpr (BITS == 4) {
-        t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0xF, true);
-        x |= t << 16;
+// ---------------------------------------------------------------------------------
+// Epilogue shared by the MFMA kernels.
+//
+// A lane owns ONE output channel c and, per 32x32 MFMA tile, 16 rows (pixels) in
+// groups of four consecutive accumulator registers.  With pooling the four registers
+// of a group are one 2x2 window.  Per value the reference computes
+//     t = ((v + bias) * inv) + shift ; code = clip(round(t * m))        (or sign bit)
+// which is monotone in v (non-decreasing for inv >= 0, non-increasing for inv < 0),
+// so max-pooling is done on the RAW conv value with max or min chosen by sign(inv):
+// exact, and 4x less epilogue arithmetic.
+//
+// Packed outputs: a lane first packs its own codes (different pixels, same channel)
+// into a register, then an in-register transpose across the lanes that share an
+// output word (8 lanes for int4, 4 for int8) leaves every lane holding one complete
+// word, so the tile is written with one dword store per lane.
+struct LaneEpi {
+    float bias, inv, shift;
+    bool neg;                 // inv < 0: pool with min
+    uint32_t selA, selB;      // v_perm selectors of the transposes
+    uint32_t maskC, rotC;     // nibble stage (int4 only)
+};
+
+template <int OUT>
+__device__ __forceinline__ void lane_epi_init(LaneEpi& k, const EpiArgs& e, int c, int li) {
+    k.bias = e.bias ? e.bias[c] : 0.0f;
+    k.inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
+    k.shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+    k.neg = k.inv < 0.0f;
+    if constexpr (OUT == QNN_STORE_I4) {
+        k.selA = (li & 4) ? 0x03020706u : 0x05040100u;
+        k.selB = (li & 2) ? 0x03070105u : 0x06020400u;
+        k.maskC = (li & 1) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+        k.rotC = (li & 1) ? 4u : 28u;
+    } else {
+        k.selA = (li & 2) ? 0x03020706u : 0x05040100u;
+        k.selB = (li & 1) ? 0x03070105u : 0x06020400u;
+        k.maskC = 0; k.rotC = 0;
     }
-    return x;
 }
 
-// Epilogue of four consecutive accumulator rows of one lane (one output channel c).
-// v[0..3]: conv results (scaled).  POOL==2: the four rows are one 2x2 pool window
-// (stored pixel q0); POOL==1: four consecutive stored pixels q0..q0+3.
-template <int OUT, int POOL>
-__device__ __forceinline__ void emit_group(float (&v)[4], float bias, float inv, float shift,
-                                           const EpiArgs& e, int c, int li, int lh, long q0,
-                                           long total_q, int cout, void* __restrict__ y) {
-    constexpr int OBITS = (OUT == QNN_STORE_BIN) ? 1 : (OUT == QNN_STORE_I4) ? 4 : (OUT == QNN_STORE_I8) ? 8 : 32;
+// BN on one value, reference op order (two roundings for the BN, one for the bias)
+__device__ __forceinline__ float bn_apply(float v, const LaneEpi& k) {
+    return __fadd_rn(__fmul_rn(__fadd_rn(v, k.bias), k.inv), k.shift);
+}
+// pool a 2x2 window on raw values (see header comment)
+__device__ __forceinline__ float pool_raw(const float (&v)[4], const LaneEpi& k) {
+    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    const float mn = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+    return k.neg ? mn : mx;
+}
+// post-BN value -> unsigned offset code (code + 2^(bits-1)); XOR-ed back to two's
+// complement after packing.  rint == round_through for finite values.
+template <int OBITS>
+__device__ __forceinline__ uint32_t ucode(float t, const EpiArgs& e) {
+    constexpr float OFF = (float)(1 << (OBITS - 1));
+    float r;
+    if (e.fn == QNN_FN_BINARY_TANH) r = (t > 0x1p-24f) ? 1.0f : -1.0f;     // binary_tanh(x)=+1 iff x>2^-24
+    else r = fminf(fmaxf(rintf(__fmul_rn(t, e.act_m)), -e.act_m), e.act_m - 1.0f);
+    return (uint32_t)(int)(r + OFF);
+}
+
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);
+}
+// 8x8 nibble transpose across the 8 lanes of an octet: in: lane i holds nibbles
+// M[i][0..7]; out: lane j holds M[0..7][j]
+__device__ __forceinline__ uint32_t transpose_nib8(uint32_t P, const LaneEpi& k) {
+    uint32_t Q = (uint32_t)__builtin_amdgcn_ds_swizzle((int)P, 0x101F);   // lane ^ 4
+    P = __builtin_amdgcn_perm(Q, P, k.selA);
+    Q = dpp_xor2(P);
+    P = __builtin_amdgcn_perm(Q, P, k.selB);
+    Q = dpp_xor1(P);
+    const uint32_t R = __builtin_amdgcn_alignbit(Q, Q, k.rotC);
+    return (P & k.maskC) | (R & ~k.maskC);
+}
+// 4x4 byte transpose across the 4 lanes of a quad
+__device__ __forceinline__ uint32_t transpose_byte4(uint32_t P, const LaneEpi& k) {
+    uint32_t Q = dpp_xor2(P);
+    P = __builtin_amdgcn_perm(Q, P, k.selA);
+    Q = dpp_xor1(P);
+    return __builtin_amdgcn_perm(Q, P, k.selB);
+}
+
+// Store NV finished (post-pool, post-BN) values of one lane.  Value j belongs to stored
+// pixel qof(j) and output channel cof(j); within one call all cof(j) agree modulo 32
+// with the lane index li, so the nibble/byte/bit position inside a word is li's.
+template <int OUT, int NV, typename QF, typename CF>
+__device__ __forceinline__ void store_values(const float (&t)[NV], const LaneEpi& k,
+                                             const EpiArgs& e, int li, QF qof, CF cof,
+                                             long total_q, int cout, void* __restrict__ y) {
+    if constexpr (OUT == QNN_STORE_F32) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float t = __fadd_rn(v[s], bias);
-        v[s] = __fadd_rn(__fmul_rn(t, inv), shift);
-    }
-    if constexpr (POOL == 2) {
-        const bool live = q0 < total_q;
-        if constexpr (OUT == QNN_STORE_F32) {
-            float r[4];
+        for (int j = 0; j < NV; ++j) {
+            float r = t[j];
+            if (e.fn == QNN_FN_BINARY_TANH) r = qnn_binary_tanh(r);
+            else if (e.fn == QNN_FN_QUANTIZED_TANH) r = qnn_quantized_tanh(r, e.act_m);
+            const long q = qof(j);
+            if (q < total_q) ((float*)y)[q * cout + cof(j)] = r;
+        }
+    } else if constexpr (OUT == QNN_STORE_BIN) {
+        // one ballot per value: bits of lanes 0-31 / 32-63 are the 32 channels of the
+        // two pixel rows; lane (j mod 32) of each half keeps word j and stores it later
+        static_assert(NV <= 32, "at most 32 values per call");
+        const bool hi = (threadIdx.x & 32) != 0;
+        uint32_t mine = 0;
+        long myq = total_q;
+        int myc = 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                r[s] = v[s];
-                if (e.fn == QNN_FN_BINARY_TANH) r[s] = qnn_binary_tanh(v[s]);
-                else if (e.fn == QNN_FN_QUANTIZED_TANH) r[s] = qnn_quantized_tanh(v[s], e.act_m);
-            }
-            const float m = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
-            if (live) ((float*)y)[q0 * cout + c] = m;
-        } else {
-            // the clip is monotone: clip(max(v)) == max(clip(v)) exactly
-            const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            const int code = qnn_epi_code(vm, e);
-            if constexpr (OUT == QNN_STORE_BIN) {
-                const unsigned long long m = __ballot(code != 0);
-                const uint32_t word = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
-                if (live && li == 0) ((uint32_t*)y)[q0 * e.ocw + (c >> 5)] = word;
-            } else {
-                const uint32_t word = pack_lanes<OBITS>(code);
-                constexpr int PW = 32 / OBITS;
-                if (live && (li % PW) == 0) ((uint32_t*)y)[q0 * e.ocw + c / PW] = word;
-            }
+        for (int j = 0; j < NV; ++j) {
+            const unsigned long long m = __ballot(t[j] > 0x1p-24f);   // binary_tanh = +1 iff x > 2^-24
+            const uint32_t w = hi ? (uint32_t)(m >> 32) : (uint32_t)m;
+            if (li == j) { mine = w; myq = qof(j); myc = cof(j); }
+        }
+        if (myq < total_q) ((uint32_t*)y)[myq * e.ocw + (myc >> 5)] = mine;
+    } else if constexpr (OUT == QNN_STORE_I4) {
+        static_assert(NV % 8 == 0, "int4 packing works on 8 values per lane");
+#pragma unroll
+        for (int g = 0; g < NV / 8; ++g) {
+            uint32_t P = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) P |= ucode<4>(t[8 * g + j], e) << (4 * j);
+            P = transpose_nib8(P, k) ^ 0x88888888u;
+            long q = total_q;
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if ((li & 7) == j) { q = qof(8 * g + j); c = cof(8 * g + j); }
+            if (q < total_q) ((uint32_t*)y)[q * e.ocw + (c >> 3)] = P;
         }
     } else {
+        static_assert(NV % 4 == 0, "int8 packing works on 4 values per lane");
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const long q = q0 + s;
-            const bool live = q < total_q;
-            if constexpr (OUT == QNN_STORE_F32) {
-                float r = v[s];
-                if (e.fn == QNN_FN_BINARY_TANH) r = qnn_binary_tanh(r);
-                else if (e.fn == QNN_FN_QUANTIZED_TANH) r = qnn_quantized_tanh(r, e.act_m);
-                if (live) ((float*)y)[q * cout + c] = r;
-            } else {
-                const int code = qnn_epi_code(v[s], e);
-                if constexpr (OUT == QNN_STORE_BIN) {
-                    const unsigned long long m = __ballot(code != 0);
-                    const uint32_t word = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
-                    if (live && li == 0) ((uint32_t*)y)[q * e.ocw + (c >> 5)] = word;
-                } else {
-                    const uint32_t word = pack_lanes<OBITS>(code);
-                    constexpr int PW = 32 / OBITS;
-                    if (live && (li % PW) == 0) ((uint32_t*)y)[q * e.ocw + c / PW] = word;
-                }
-            }
+        for (int g = 0; g < NV / 4; ++g) {
+            uint32_t P = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) P |= ucode<8>(t[4 * g + j], e) << (8 * j);
+            P = transpose_byte4(P, k) ^ 0x80808080u;
+            long q = total_q;
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((li & 3) == j) { q = qof(4 * g + j); c = cof(4 * g + j); }
+            if (q < total_q) ((uint32_t*)y)[q * e.ocw + (c >> 2)] = P;
         }
     }
 }
@@ -248,20 +317,31 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int c = nbase + wn * 64 + b * 32 + li;
-        const float bias = e.bias ? e.bias[c] : 0.0f;
-        const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
-        const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+        LaneEpi k;
+        lane_epi_init<OUT>(k, e, c, li);
+        if constexpr (POOL == 2) {
+            float t[8];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                // rows 8*g4 + 4*lh + 0..3 of this 32-row MFMA tile sit in regs 4*g4..4*g4+3
-                float v[4];
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float w[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) v[s] = __fmul_rn((float)acc[a][b][4 * g4 + s], e.scale);
-                const int R0 = wm * 64 + a * 32 + 8 * g4 + 4 * lh;   // tile row of v[0]
-                const long q0 = (POOL == 2) ? tile * (BM / 4) + (R0 >> 2) : tile * BM + R0;
-                emit_group<OUT, POOL>(v, bias, inv, shift, e, c, li, lh, q0, mg.total_q, g.cout, y);
+                    for (int s = 0; s < 4; ++s) w[s] = __fmul_rn((float)acc[a][b][4 * g4 + s], e.scale);
+                    t[a * 4 + g4] = bn_apply(pool_raw(w, k), k);
+                }
+            store_values<OUT, 8>(t, k, e, li,
+                [&](int j) { return tile * (BM / 4) + ((wm * 64 + (j >> 2) * 32 + 8 * (j & 3) + 4 * lh) >> 2); },
+                [&](int) { return c; }, mg.total_q, g.cout, y);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = bn_apply(__fmul_rn((float)acc[a][b][r], e.scale), k);
+                store_values<OUT, 16>(t, k, e, li,
+                    [&](int j) { return tile * BM + wm * 64 + a * 32 + (j & 3) + 8 * (j >> 2) + 4 * lh; },
+                    [&](int) { return c; }, mg.total_q, g.cout, y);
             }
         }
     }
@@ -327,14 +407,9 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
             const int k = 2 * s + lh;
             wb[nt][s] = k < K ? wq[(long)(nt * 32 + li) * K + k] : 0.0f;
         }
-    float bias[NT], inv[NT], shift[NT];
+    LaneEpi ke[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int c = nt * 32 + li;
-        bias[nt] = e.bias ? e.bias[c] : 0.0f;
-        inv[nt] = e.bn_inv ? e.bn_inv[c] : 1.0f;
-        shift[nt] = e.bn_inv ? e.bn_shift[c] : 0.0f;
-    }
+    for (int nt = 0; nt < NT; ++nt) lane_epi_init<OUT>(ke[nt], e, nt * 32 + li, li);
 
     // A operand of tile `t`: lane (li, lh) supplies x[pixel li][k = 2s+lh]; only the
     // address offset differs between the two lane halves, and both candidates are
@@ -390,17 +465,28 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], wb[nt][s], acc[nt], 0, 0, 0);
         }
         // ---- epilogue ----
+        if constexpr (POOL == 2) {
+            float t[NT * 4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int c = nt * 32 + li;
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                float v[4];
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float w[4] = {acc[nt][4 * g4], acc[nt][4 * g4 + 1], acc[nt][4 * g4 + 2],
+                                        acc[nt][4 * g4 + 3]};
+                    t[nt * 4 + g4] = bn_apply(pool_raw(w, ke[nt]), ke[nt]);
+                }
+            store_values<OUT, NT * 4>(t, ke[0], e, li,
+                [&](int j) { return tile * 8 + 2 * (j & 3) + lh; },
+                [&](int j) { return (j >> 2) * 32 + li; }, total_q, g.cout, y);
+        } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) v[s] = acc[nt][4 * g4 + s];
-                const int R0 = 8 * g4 + 4 * lh;
-                const long q0 = (POOL == 2) ? tile * 8 + (R0 >> 2) : tile * 32 + R0;
-                emit_group<OUT, POOL>(v, bias[nt], inv[nt], shift[nt], e, c, li, lh, q0, total_q, g.cout, y);
+            for (int nt = 0; nt < NT; ++nt) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = bn_apply(acc[nt][r], ke[nt]);
+                store_values<OUT, 16>(t, ke[nt], e, li,
+                    [&](int j) { return tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * lh; },
+                    [&](int) { return nt * 32 + li; }, total_q, g.cout, y);
             }
         }
         if (more) {
