@@ -89,13 +89,24 @@ __device__ __forceinline__ float pool_raw(const float (&v)[4], const LaneEpi& k)
 }
 // post-BN value -> unsigned offset code (code + 2^(bits-1)); XOR-ed back to two's
 // complement after packing.  rint == round_through for finite values.
-template <int OBITS>
+template <int OBITS, bool BIN>
 __device__ __forceinline__ uint32_t ucode(float t, const EpiArgs& e) {
-    constexpr float OFF = (float)(1 << (OBITS - 1));
-    float r;
-    if (e.fn == QNN_FN_BINARY_TANH) r = (t > 0x1p-24f) ? 1.0f : -1.0f;     // binary_tanh(x)=+1 iff x>2^-24
-    else r = fminf(fmaxf(rintf(__fmul_rn(t, e.act_m)), -e.act_m), e.act_m - 1.0f);
-    return (uint32_t)(int)(r + OFF);
+    constexpr int OFF = 1 << (OBITS - 1);
+    if constexpr (BIN) return (t > 0x1p-24f) ? (uint32_t)(OFF + 1) : (uint32_t)(OFF - 1);   // +1 iff x > 2^-24
+    const float r = __builtin_amdgcn_fmed3f(rintf(__fmul_rn(t, e.act_m)), -e.act_m, e.act_m - 1.0f);
+    return (uint32_t)((int)r + OFF);
+}
+template <int OBITS, int N>
+__device__ __forceinline__ uint32_t pack_own(const float* t, const EpiArgs& e) {
+    uint32_t P = 0;
+    if (e.fn == QNN_FN_BINARY_TANH) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) P |= ucode<OBITS, true>(t[j], e) << (OBITS * j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) P |= ucode<OBITS, false>(t[j], e) << (OBITS * j);
+    }
+    return P;
 }
 
 __device__ __forceinline__ uint32_t dpp_xor1(uint32_t x) {
@@ -158,9 +169,7 @@ __device__ __forceinline__ void store_values(const float (&t)[NV], const LaneEpi
         static_assert(NV % 8 == 0, "int4 packing works on 8 values per lane");
 #pragma unroll
         for (int g = 0; g < NV / 8; ++g) {
-            uint32_t P = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) P |= ucode<4>(t[8 * g + j], e) << (4 * j);
+            uint32_t P = pack_own<4, 8>(&t[8 * g], e);
             P = transpose_nib8(P, k) ^ 0x88888888u;
             long q = total_q;
             int c = 0;
@@ -173,9 +182,7 @@ __device__ __forceinline__ void store_values(const float (&t)[NV], const LaneEpi
         static_assert(NV % 4 == 0, "int8 packing works on 4 values per lane");
 #pragma unroll
         for (int g = 0; g < NV / 4; ++g) {
-            uint32_t P = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) P |= ucode<8>(t[4 * g + j], e) << (8 * j);
+            uint32_t P = pack_own<8, 4>(&t[4 * g], e);
             P = transpose_byte4(P, k) ^ 0x80808080u;
             long q = total_q;
             int c = 0;
@@ -386,11 +393,11 @@ int launch_out(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 template <int CIN, int NT, int OUT, int POOL>   // NT = cout / 32
-__global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
+__global__ __launch_bounds__(256, 3) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
                                                          const float* __restrict__ x,
                                                          const float* __restrict__ wq,
                                                          void* __restrict__ y, long total_q,
-                                                         long tiles) {
+                                                         long tiles, uint32_t x_bytes) {
     constexpr int K = 9 * CIN;
     constexpr int KS = (K + 1) / 2;          // MFMA k-steps of 2
     const int lane = threadIdx.x & 63;
@@ -411,6 +418,8 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) lane_epi_init<OUT>(ke[nt], e, nt * 32 + li, li);
 
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
     // A operand of tile `t`: lane (li, lh) supplies x[pixel li][k = 2s+lh]; only the
     // address offset differs between the two lane halves, and both candidates are
     // wave-uniform, so the gather is KS predicated dword loads per lane.
@@ -432,18 +441,20 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
                 inb[dy * 3 + dx] = (unsigned)(iy0 + dy) < (unsigned)g.H && (unsigned)(ix0 + dx) < (unsigned)g.W;
-        const long base = (((long)n * g.H + iy0) * g.W + ix0) * CIN;
+        // byte offset of the receptive field's top-left pixel; taps outside the image
+        // get an offset past the end of the buffer, which a raw buffer load returns as 0
+        const int base4 = (((n * g.H + iy0) * g.W + ix0) * CIN) * 4;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            constexpr int dummy = 0; (void)dummy;
             const int ke = 2 * s, ko = 2 * s + 1;
             const int te = ke / CIN, ce = ke % CIN;
             const int to = (ko < K) ? ko / CIN : 0, co = (ko < K) ? ko % CIN : 0;
-            const int off_e = ((te / 3) * g.W + (te % 3)) * CIN + ce;
-            const int off_o = ((to / 3) * g.W + (to % 3)) * CIN + co;
+            const int off_e = (((te / 3) * g.W + (te % 3)) * CIN + ce) * 4;
+            const int off_o = (((to / 3) * g.W + (to % 3)) * CIN + co) * 4;
             const bool ok = lh ? (ko < K && inb[to]) : inb[te];
             const int off = lh ? off_o : off_e;
-            av[s] = ok ? x[base + off] : 0.0f;
+            const uint32_t voff = ok ? (uint32_t)(base4 + off) : 0xFFFFFFF0u;
+            av[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)voff, 0, 0));
         }
     };
 
@@ -507,12 +518,15 @@ int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float
     if (blocks > max_blocks) blocks = max_blocks;
     const dim3 grid((unsigned)blocks), block(256);
     const float* xf = (const float*)x;
+    const double xb = (double)g.N * g.H * g.W * CIN * 4.0;
+    if (xb >= 4.0e9) return 1;                  // 32-bit buffer offsets
+    const uint32_t x_bytes = (uint32_t)xb;
 #define FIRST_CASE(OUT)                                                                      \
     if (e.out_store == OUT) {                                                                \
         if (g.pool == 2)                                                                     \
-            hipLaunchKernelGGL((k_conv_first_mfma<CIN, NT, OUT, 2>), grid, block, 0, s, g, e, xf, wq, y, total_q, tiles); \
+            hipLaunchKernelGGL((k_conv_first_mfma<CIN, NT, OUT, 2>), grid, block, 0, s, g, e, xf, wq, y, total_q, tiles, x_bytes); \
         else                                                                                 \
-            hipLaunchKernelGGL((k_conv_first_mfma<CIN, NT, OUT, 1>), grid, block, 0, s, g, e, xf, wq, y, total_q, tiles); \
+            hipLaunchKernelGGL((k_conv_first_mfma<CIN, NT, OUT, 1>), grid, block, 0, s, g, e, xf, wq, y, total_q, tiles, x_bytes); \
         return 0;                                                                            \
     }
     FIRST_CASE(QNN_STORE_F32)
