@@ -35,6 +35,7 @@ struct MfmaGeom {
     int steps;         // kh*kw*kc
     int x_pix_bytes;   // bytes per input pixel as stored
     long total_q;      // stored output pixels
+    uint32_t x_bytes, w_bytes;   // sizes of the x tensor / int8 weight image (buffer descriptors)
 };
 
 // ---------------------------------------------------------------------------------
@@ -204,12 +205,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int RPP = T / 4;               // rows staged per pass
     constexpr int NA = BM / RPP, NB = BN / RPP;
+    constexpr int XCH = (XS == QNN_STORE_I8) ? 16 : 8;     // stored bytes per 16-channel chunk
     static_assert(NA >= 1 && NB >= 1, "tile too small for the workgroup");
     const ConvGeom& g = mg.g;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const lds_a = smem;                          // [2][BM*64]
-    char* const lds_b = smem + 2 * BM * 64;            // [2][BN*64]
+    constexpr int A_BUF = BM * 64, B_BUF = BN * 64;
+    constexpr int B_BASE = 2 * A_BUF;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,9 +220,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
     const long tile = blockIdx.x;
     const int nbase = blockIdx.y * BN;
 
-    // ---- per-thread staging rows -------------------------------------------------
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(x), 0, (int)mg.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
+
+    // ---- per-thread staging rows: byte offset of the receptive field's top-left
+    // pixel (+ this thread's chunk) and a 9-bit "tap is inside the image" mask --------
     const int srow = tid >> 2, sch = tid & 3;
-    int a_pix0[NA], a_iy0[NA], a_ix0[NA];
+    int a_voff[NA];
+    uint32_t a_mask[NA];
+    int a_lds[NA], b_lds[NB], b_voff[NB];
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
         const int R = srow + p * RPP;
@@ -228,61 +238,72 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
         int sub = 0;
         if constexpr (POOL == 2) { q = tile * (BM / 4) + (R >> 2); sub = R & 3; }
         else q = tile * BM + R;
+        a_mask[p] = 0;
+        a_voff[p] = 0;
         if (q < mg.total_q) {
             const uint32_t qrow = qnn_div((uint32_t)q, g.fd_wp);
             const int px = (int)((uint32_t)q - qrow * g.Wp);
             const int n = (int)qnn_div(qrow, g.fd_hp);
             const int py = (int)(qrow - (uint32_t)n * g.Hp);
-            const int oy = py * POOL + (sub >> 1), ox = px * POOL + (sub & 1);
-            a_iy0[p] = oy * g.stride - g.pt;
-            a_ix0[p] = ox * g.stride - g.pl;
-            a_pix0[p] = (n * g.H + a_iy0[p]) * g.W + a_ix0[p];
-        } else {
-            a_iy0[p] = -100000; a_ix0[p] = -100000; a_pix0[p] = 0;   // never in range -> zeros
+            const int iy0 = (py * POOL + (sub >> 1)) * g.stride - g.pt;
+            const int ix0 = (px * POOL + (sub & 1)) * g.stride - g.pl;
+            a_voff[p] = ((n * g.H + iy0) * g.W + ix0) * mg.x_pix_bytes + sch * XCH;
+            for (int dy = 0; dy < g.kh; ++dy)
+                for (int dx = 0; dx < g.kw; ++dx)
+                    if ((unsigned)(iy0 + dy) < (unsigned)g.H && (unsigned)(ix0 + dx) < (unsigned)g.W)
+                        a_mask[p] |= 1u << (dy * g.kw + dx);
         }
+        a_lds[p] = R * 64 + ((sch ^ ((R >> 2) & 3)) << 4);
     }
-    const long w_row_bytes = (long)g.kh * g.kw * g.cin;   // int8 bytes per cout
+    const int w_row_bytes = g.kh * g.kw * g.cin;   // int8 bytes per cout
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        const int R = srow + p * RPP;
+        b_voff[p] = (nbase + R) * w_row_bytes + sch * 16;
+        b_lds[p] = B_BASE + R * 64 + ((sch ^ ((R >> 2) & 3)) << 4);
+    }
 
+    // ---- fragment read addresses (constant per lane) -----------------------------------
+    const int li = lane & 31, lh = lane >> 5;
+    int fa_addr[2][2], fb_addr[2][2];   // [tile t][kk]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ra_ = wm * 64 + t * 32 + li;
+            fa_addr[t][kk] = ra_ * 64 + (((kk * 2 + lh) ^ ((ra_ >> 2) & 3)) << 4);
+            const int rb_ = wn * 64 + t * 32 + li;
+            fb_addr[t][kk] = B_BASE + rb_ * 64 + (((kk * 2 + lh) ^ ((rb_ >> 2) & 3)) << 4);
+        }
+
+    // uniform K-step state, advanced incrementally (no divisions in the loop)
+    int s_tap = 0, s_kc = 0, s_dy = 0, s_dx = 0;
     uint4 ra[NA], rb[NB];
-    auto stage_load = [&](int ks) {
-        const int tap = ks / mg.kc, kc = ks - tap * mg.kc;
-        const int dy = tap / g.kw, dx = tap - dy * g.kw;
+    auto stage_load = [&]() {
+        const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
+        const int woff = s_tap * g.cin + s_kc * 64;
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
-            const int iy = a_iy0[p] + dy, ix = a_ix0[p] + dx;
-            const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-            const long pix = (long)a_pix0[p] + dy * g.W + dx;
+            const bool ok = (a_mask[p] >> s_tap) & 1u;
+            const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;   // out of range -> zeros
             if constexpr (XS == QNN_STORE_I8) {
-                const uint8_t* src = x + pix * mg.x_pix_bytes + kc * 64 + sch * 16;
-                ra[p] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+                ra[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
             } else {
-                const uint8_t* src = x + pix * mg.x_pix_bytes + kc * 32 + sch * 8;
-                const uint2 v = ok ? *reinterpret_cast<const uint2*>(src) : make_uint2(0, 0);
+                const uint2 v = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0));
                 ra[p] = make_uint4((v.x << 4) & 0xF0F0F0F0u, v.x & 0xF0F0F0F0u,
                                    (v.y << 4) & 0xF0F0F0F0u, v.y & 0xF0F0F0F0u);
             }
         }
 #pragma unroll
-        for (int p = 0; p < NB; ++p) {
-            const int R = srow + p * RPP;
-            const uint8_t* src = wq8 + (long)(nbase + R) * w_row_bytes + (long)tap * g.cin + kc * 64 + sch * 16;
-            rb[p] = *reinterpret_cast<const uint4*>(src);
-        }
-    };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < NA; ++p) {
-            const int R = srow + p * RPP;
-            *reinterpret_cast<uint4*>(lds_a + buf * (BM * 64) + R * 64 + ((sch ^ ((R >> 2) & 3)) << 4)) = ra[p];
-        }
-#pragma unroll
-        for (int p = 0; p < NB; ++p) {
-            const int R = srow + p * RPP;
-            *reinterpret_cast<uint4*>(lds_b + buf * (BN * 64) + R * 64 + ((sch ^ ((R >> 2) & 3)) << 4)) = rb[p];
+        for (int p = 0; p < NB; ++p)
+            rb[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_voff[p], woff, 0));
+        // advance (tap, kc)
+        if (++s_kc == mg.kc) {
+            s_kc = 0; ++s_tap;
+            if (++s_dx == g.kw) { s_dx = 0; ++s_dy; }
         }
     };
 
-    // ---- main loop ----------------------------------------------------------------
     v16i acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -291,24 +312,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
 
-    const int li = lane & 31, lh = lane >> 5;
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-    for (int ks = 0; ks < mg.steps; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < mg.steps) stage_load(ks + 1);
+    auto stage_write = [&](int bufoff_a, int bufoff_b) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) *reinterpret_cast<uint4*>(smem + a_lds[p] + bufoff_a) = ra[p];
+#pragma unroll
+        for (int p = 0; p < NB; ++p) *reinterpret_cast<uint4*>(smem + b_lds[p] + bufoff_b) = rb[p];
+    };
+    auto compute = [&](int bufoff_a, int bufoff_b) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             v4i fa[2], fb[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int ra_ = wm * 64 + t * 32 + li;
-                fa[t] = *reinterpret_cast<const v4i*>(lds_a + buf * (BM * 64) + ra_ * 64 +
-                                                      (((kk * 2 + lh) ^ ((ra_ >> 2) & 3)) << 4));
-                const int rb_ = wn * 64 + t * 32 + li;
-                fb[t] = *reinterpret_cast<const v4i*>(lds_b + buf * (BN * 64) + rb_ * 64 +
-                                                      (((kk * 2 + lh) ^ ((rb_ >> 2) & 3)) << 4));
+                fa[t] = *reinterpret_cast<const v4i*>(smem + fa_addr[t][kk] + bufoff_a);
+                fb[t] = *reinterpret_cast<const v4i*>(smem + fb_addr[t][kk] + bufoff_b);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -316,9 +333,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
-        if (ks + 1 < mg.steps) stage_write(buf ^ 1);
+    };
+
+    // ---- main loop: one barrier per K-step, next tile's loads in flight over the MFMAs ----
+    stage_load();
+    stage_write(0, 0);
+    __syncthreads();
+    int ks = 0;
+    for (; ks + 1 < mg.steps; ks += 2) {
+        stage_load();                      // step ks+1
+        compute(0, 0);
+        stage_write(A_BUF, B_BUF);
+        __syncthreads();
+        const bool more = ks + 2 < mg.steps;
+        if (more) stage_load();            // step ks+2
+        compute(A_BUF, B_BUF);
+        if (more) stage_write(0, 0);
         __syncthreads();
     }
+    if (ks < mg.steps) compute(0, 0);      // odd step count: last step sits in buffer 0
 
     // ---- epilogue -------------------------------------------------------------------
 #pragma unroll
@@ -332,10 +365,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    float w[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) w[s] = __fmul_rn((float)acc[a][b][4 * g4 + s], e.scale);
-                    t[a * 4 + g4] = bn_apply(pool_raw(w, k), k);
+                    // int -> float -> *2^-s is monotone: pool on the integer accumulators
+                    const int i0 = acc[a][b][4 * g4], i1 = acc[a][b][4 * g4 + 1];
+                    const int i2 = acc[a][b][4 * g4 + 2], i3 = acc[a][b][4 * g4 + 3];
+                    const int mx = max(max(i0, i1), max(i2, i3));
+                    const int mn = min(min(i0, i1), min(i2, i3));
+                    t[a * 4 + g4] = bn_apply(__fmul_rn((float)(k.neg ? mn : mx), e.scale), k);
                 }
             store_values<OUT, 8>(t, k, e, li,
                 [&](int j) { return tile * (BM / 4) + ((wm * 64 + (j >> 2) * 32 + 8 * (j & 3) + 4 * lh) >> 2); },
@@ -593,6 +628,11 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     mg.steps = g.kh * g.kw * mg.kc;
     mg.x_pix_bytes = x_store == QNN_STORE_I8 ? g.cin : g.cin / 2;
     mg.total_q = (long)g.N * g.Hp * g.Wp;
+    const double xb = (double)g.N * g.H * g.W * mg.x_pix_bytes;
+    const double wb = (double)g.cout * g.kh * g.kw * g.cin;
+    if (xb >= 2.0e9 || wb >= 2.0e9) return 1;          // 31-bit buffer offsets
+    mg.x_bytes = (uint32_t)xb;
+    mg.w_bytes = (uint32_t)wb;
     EpiArgs e2 = e;
     if (x_store == QNN_STORE_I4) e2.scale = e.scale * (1.0f / 256.0f);   // both operands carry *16
     const bool wide = (g.cout % 128) == 0;
