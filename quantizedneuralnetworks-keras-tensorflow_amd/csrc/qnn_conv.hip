@@ -337,6 +337,60 @@ __global__ __launch_bounds__(kBlock) void k_conv_ps(ConvGeom g, EpiArgs e,
 }
 
 // ---------------------------------------------------------------------------
+// dense layer on packed activations (BinaryDense.call / QuantizedDense.call,
+// binary_layers.py:78-85, quantized_layers.py:79-88): thread = (image, unit), the
+// UP unit-slots of one image sit in adjacent lanes so the activation words are a
+// broadcast load; weights (<= a few KB) stay in L1.  float32 output, full epilogue.
+// ---------------------------------------------------------------------------
+template <int XS, int UP>
+__global__ __launch_bounds__(kBlock) void k_dense_packed(const uint32_t* __restrict__ x,
+                                                         const uint32_t* __restrict__ wp, EpiArgs e,
+                                                         float* __restrict__ y, int N, int cin,
+                                                         int kwords, int units) {
+    constexpr int IPB = kBlock / UP;                 // images per block
+    const int u = threadIdx.x % UP;
+    const int img = blockIdx.x * IPB + threadIdx.x / UP;
+    if (img >= N || u >= units) return;
+    const uint32_t* xr = x + (size_t)img * kwords;
+    const uint32_t* wr = wp + (size_t)u * kwords;
+    int acc = 0;
+    int k = 0;
+    for (; k + 4 <= kwords; k += 4) {
+        const uint4 a = *reinterpret_cast<const uint4*>(xr + k);
+        const uint4 w = *reinterpret_cast<const uint4*>(wr + k);
+        acc = qnn_dot<XS>(a.x, w.x, acc);
+        acc = qnn_dot<XS>(a.y, w.y, acc);
+        acc = qnn_dot<XS>(a.z, w.z, acc);
+        acc = qnn_dot<XS>(a.w, w.w, acc);
+    }
+    for (; k < kwords; ++k) acc = qnn_dot<XS>(xr[k], wr[k], acc);
+    if constexpr (XS == QNN_STORE_BIN) acc = cin - 2 * acc;   // pad bits are 0 in both operands
+    float v = __fmul_rn((float)acc, e.scale);
+    v = qnn_epi_value(v, u, e);
+    if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
+    else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
+    y[(size_t)img * units + u] = v;
+}
+
+template <int XS>
+int launch_dense(const void* x, const qnn_weights* w, const EpiArgs& e, void* y, int N, hipStream_t s) {
+    const int units = w->cout;
+    const uint32_t* xu = (const uint32_t*)x;
+#define DENSE_CASE(UP)                                                                           \
+    if (units <= UP) {                                                                           \
+        const int ipb = kBlock / UP;                                                             \
+        hipLaunchKernelGGL((k_dense_packed<XS, UP>), dim3((N + ipb - 1) / ipb), dim3(kBlock), 0, s, xu, \
+                           w->d_packed, e, (float*)y, N, w->cin, w->kwords, units);              \
+        return 0;                                                                                \
+    }
+    DENSE_CASE(16)
+    DENSE_CASE(64)
+    DENSE_CASE(256)
+#undef DENSE_CASE
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------
 template <int XS, int CW, int K>
@@ -489,7 +543,16 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     // required: the remainder row/column is simply never produced)
     const int pref = qnn_conv_impl_pref();
     bool launched = false;
-    if (pref != 1 && !dense)
+    if (dense && x_store != QNN_STORE_F32 && e.out_store == QNN_STORE_F32 && (w->kwords % 4) == 0) {
+        int rc2 = x_store == QNN_STORE_BIN  ? launch_dense<QNN_STORE_BIN>(x, w, e, y, N, s)
+                  : x_store == QNN_STORE_I4 ? launch_dense<QNN_STORE_I4>(x, w, e, y, N, s)
+                                            : launch_dense<QNN_STORE_I8>(x, w, e, y, N, s);
+        if (rc2 == 0) {
+            launched = true;
+            snprintf(name, sizeof(name), "dense_%s", x_store == QNN_STORE_BIN ? "bin" : x_store == QNN_STORE_I4 ? "i4" : "i8");
+        }
+    }
+    if (!launched && pref != 1 && !dense)
         launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
     if (!launched) launched = try_launch_ps(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
     if (launched) {

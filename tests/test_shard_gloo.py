@@ -1,0 +1,69 @@
+"""N>1 path on CPU: two gloo ranks shard a batch, run a (CPU stand-in) per-image
+forward and all-gather the logits; the result must equal the single-rank result.
+The sharding / gather code is the same one bench.py uses with RCCL on the GPU box."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from qnn_amd import shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_forward(x):
+    # any per-image function stands in for the GPU forward (which has no CPU path)
+    w = torch.arange(x[0].numel() * 10, dtype=torch.float32).reshape(-1, 10) / 1000.0
+    return torch.tanh(x.reshape(x.shape[0], -1) @ w)
+
+
+def _worker(rank, world, port, total, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand((total, 4, 4, 3), generator=g)
+        y = shard.sharded_forward(_fake_forward, x, rank, world)
+        lo, hi, _ = shard.shard_bounds(total, rank, world)
+        m = shard.allreduce_mean_abs((x * 4 - 2)[lo:hi])      # unpadded rows of this rank
+        if rank == 0:
+            torch.save({"y": y, "m": m}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(total, world, tmp_path):
+    out = str(tmp_path / ("out_%d_%d.pt" % (total, world)))
+    mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    return torch.load(out, weights_only=True)
+
+
+def test_shard_bounds():
+    assert shard.shard_bounds(4096, 3, 8) == (1536, 2048, 512)
+    assert shard.shard_bounds(10, 3, 4) == (9, 10, 3)
+    assert shard.shard_bounds(10, 0, 1) == (0, 10, 10)
+    x = torch.arange(10.0).reshape(10, 1)
+    parts = [shard.shard_batch(x, r, 4) for r in range(4)]
+    assert all(p.shape == (3, 1) for p in parts)
+    assert torch.equal(torch.cat(parts)[:10], x) and float(parts[3][1:].abs().sum()) == 0
+
+
+def test_two_ranks_equal_single_rank(tmp_path):
+    g = torch.Generator().manual_seed(0)
+    for total in (16, 13):                      # even split and ragged (padded) split
+        x = torch.rand((total, 4, 4, 3), generator=g.manual_seed(0))
+        want = _fake_forward(x)
+        got = _run(total, 2, tmp_path)
+        assert got["y"].shape == want.shape
+        assert torch.equal(got["y"], want)
+        ref = (x * 4 - 2).clamp(-1, 1).abs().double().mean().float()
+        assert abs(float(got["m"]) - float(ref)) < 1e-6
