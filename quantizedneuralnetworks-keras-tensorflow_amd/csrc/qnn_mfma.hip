@@ -428,7 +428,7 @@ int launch_out(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 template <int CIN, int NT, int OUT, int POOL>   // NT = cout / 32
-__global__ __launch_bounds__(256, 3) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
+__global__ __launch_bounds__(256, (NT <= 2 ? 3 : 2)) void k_conv_first_mfma(ConvGeom g, EpiArgs e,
                                                          const float* __restrict__ x,
                                                          const float* __restrict__ wq,
                                                          void* __restrict__ y, long total_q,
@@ -439,19 +439,20 @@ __global__ __launch_bounds__(256, 3) void k_conv_first_mfma(ConvGeom g, EpiArgs 
     const int li = lane & 31, lh = lane >> 5;
     const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
+    const int cbase = blockIdx.y * (NT * 32);      // this block's slice of output channels
 
-    // B operand: lane (li, lh) holds w[k = 2s+lh][cout = nt*32 + li]
+    // B operand: lane (li, lh) holds w[k = 2s+lh][cout = cbase + nt*32 + li]
     float wb[NT][KS];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int k = 2 * s + lh;
-            wb[nt][s] = k < K ? wq[(long)(nt * 32 + li) * K + k] : 0.0f;
+            wb[nt][s] = k < K ? wq[(long)(cbase + nt * 32 + li) * K + k] : 0.0f;
         }
     LaneEpi ke[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) lane_epi_init<OUT>(ke[nt], e, nt * 32 + li, li);
+    for (int nt = 0; nt < NT; ++nt) lane_epi_init<OUT>(ke[nt], e, cbase + nt * 32 + li, li);
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
@@ -498,41 +499,44 @@ __global__ __launch_bounds__(256, 3) void k_conv_first_mfma(ConvGeom g, EpiArgs 
     for (long tile = wave_id; tile < tiles; tile += nwaves) {
         const bool more = tile + nwaves < tiles;
         if (more) load_tile(tile + nwaves, nxt);
-        // ---- K-ordered MFMA chain ----
-        v16f acc[NT];
+        // ---- K-ordered MFMA chains, two 32-channel blocks at a time ----
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nc = 0; nc < NT; nc += 2) {
+            v16f acc[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+                for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], wb[nt][s], acc[nt], 0, 0, 0);
-        }
-        // ---- epilogue ----
-        if constexpr (POOL == 2) {
-            float t[NT * 4];
+            for (int s = 0; s < KS; ++s) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int u = 0; u < 2; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], wb[nc + u][s], acc[u], 0, 0, 0);
+            }
+            // ---- epilogue ----
+            if constexpr (POOL == 2) {
+                float t[8];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float w[4] = {acc[nt][4 * g4], acc[nt][4 * g4 + 1], acc[nt][4 * g4 + 2],
-                                        acc[nt][4 * g4 + 3]};
-                    t[nt * 4 + g4] = bn_apply(pool_raw(w, ke[nt]), ke[nt]);
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float w[4] = {acc[u][4 * g4], acc[u][4 * g4 + 1], acc[u][4 * g4 + 2],
+                                            acc[u][4 * g4 + 3]};
+                        t[u * 4 + g4] = bn_apply(pool_raw(w, ke[nc + u]), ke[nc + u]);
+                    }
+                store_values<OUT, 8>(t, ke[0], e, li,
+                    [&](int j) { return tile * 8 + 2 * (j & 3) + lh; },
+                    [&](int j) { return cbase + (nc + (j >> 2)) * 32 + li; }, total_q, g.cout, y);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float t[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = bn_apply(acc[u][r], ke[nc + u]);
+                    store_values<OUT, 16>(t, ke[nc + u], e, li,
+                        [&](int j) { return tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * lh; },
+                        [&](int) { return cbase + (nc + u) * 32 + li; }, total_q, g.cout, y);
                 }
-            store_values<OUT, NT * 4>(t, ke[0], e, li,
-                [&](int j) { return tile * 8 + 2 * (j & 3) + lh; },
-                [&](int j) { return (j >> 2) * 32 + li; }, total_q, g.cout, y);
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float t[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = bn_apply(acc[nt][r], ke[nt]);
-                store_values<OUT, 16>(t, ke[nt], e, li,
-                    [&](int j) { return tile * 32 + (j & 3) + 8 * (j >> 2) + 4 * lh; },
-                    [&](int) { return nt * 32 + li; }, total_q, g.cout, y);
             }
         }
         if (more) {
@@ -549,9 +553,10 @@ int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float
     const long rows = total_q * (g.pool == 2 ? 4 : 1);
     const long tiles = (rows + 31) / 32;
     long blocks = (tiles + 3) / 4;
-    const long max_blocks = 256 * 4;            // persistent: 4 blocks (16 waves) per CU
+    const int ny = g.cout / (NT * 32);          // channel slices (blockIdx.y)
+    const long max_blocks = 256 * 4 / ny;       // persistent: ~4 blocks (16 waves) per CU in total
     if (blocks > max_blocks) blocks = max_blocks;
-    const dim3 grid((unsigned)blocks), block(256);
+    const dim3 grid((unsigned)blocks, (unsigned)ny), block(256);
     const float* xf = (const float*)x;
     const double xb = (double)g.N * g.H * g.W * CIN * 4.0;
     if (xb >= 4.0e9) return 1;                  // 32-bit buffer offsets
@@ -610,12 +615,16 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                         const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len) {
     if (x_store == QNN_STORE_F32) {
         // float-input first layer on the f32 matrix pipe
-        if (g.kh != 3 || g.kw != 3 || (g.cin != 1 && g.cin != 3) || g.cout != 64) return 1;
+        if (g.kh != 3 || g.kw != 3 || (g.cin != 1 && g.cin != 3)) return 1;
+        if (g.cout != 64 && g.cout != 128 && g.cout != 256) return 1;
         const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
         if (g.cout % pw != 0) return 1;
         snprintf(name, name_len, "mfma_f32_first_cin%d", g.cin);
-        return g.cin == 3 ? launch_first<3, 2>(g, e, x, w->d_wq, y, s)
-                          : launch_first<1, 2>(g, e, x, w->d_wq, y, s);
+        if (g.cout == 64)
+            return g.cin == 3 ? launch_first<3, 2>(g, e, x, w->d_wq, y, s) : launch_first<1, 2>(g, e, x, w->d_wq, y, s);
+        if (g.cout == 128)
+            return g.cin == 3 ? launch_first<3, 4>(g, e, x, w->d_wq, y, s) : launch_first<1, 4>(g, e, x, w->d_wq, y, s);
+        return g.cin == 3 ? launch_first<3, 4>(g, e, x, w->d_wq, y, s) : launch_first<1, 4>(g, e, x, w->d_wq, y, s);
     }
     if (!w->d_mfma) return 1;
     if (x_store != QNN_STORE_I8 && x_store != QNN_STORE_I4) return 1;
