@@ -197,7 +197,7 @@ __device__ __forceinline__ void store_values(const float (&t)[NV], const LaneEpi
 
 // XS: QNN_STORE_I8 or QNN_STORE_I4 (storage of x; weights are always int8 bytes here)
 template <int XS, int WM, int WN, int OUT, int POOL>
-__global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs e,
+__global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(MfmaGeom mg, EpiArgs e,
                                                            const uint8_t* __restrict__ x,
                                                            const uint8_t* __restrict__ wq8,
                                                            void* __restrict__ y) {
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
 
     // uniform K-step state, advanced incrementally (no divisions in the loop)
     int s_tap = 0, s_kc = 0, s_dy = 0, s_dx = 0;
-    uint4 ra[NA], rb[NB];
-    auto stage_load = [&]() {
+    uint4 raA[NA], rbA[NB], raB[NA], rbB[NB];     // two staging register sets (2-deep prefetch)
+    auto stage_load = [&](uint4 (&ra)[NA], uint4 (&rb)[NB]) {
         const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
         const int woff = s_tap * g.cin + s_kc * 64;
 #pragma unroll
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
 
-    auto stage_write = [&](int bufoff_a, int bufoff_b) {
+    auto stage_write = [&](const uint4 (&ra)[NA], const uint4 (&rb)[NB], int bufoff_a, int bufoff_b) {
 #pragma unroll
         for (int p = 0; p < NA; ++p) *reinterpret_cast<uint4*>(smem + a_lds[p] + bufoff_a) = ra[p];
 #pragma unroll
@@ -335,23 +335,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(MfmaGeom mg, EpiArgs
         }
     };
 
-    // ---- main loop: one barrier per K-step, next tile's loads in flight over the MFMAs ----
-    stage_load();
-    stage_write(0, 0);
+    // ---- main loop: one barrier per K-step; the loads of step k+2 are issued before the
+    // MFMAs of step k and only waited for (counted vmcnt) after the MFMAs of step k+1 ----
+    const int S = mg.steps;
+    stage_load(raA, rbA);                          // step 0
+    if (S > 1) stage_load(raB, rbB);               // step 1
+    stage_write(raA, rbA, 0, 0);
     __syncthreads();
     int ks = 0;
-    for (; ks + 1 < mg.steps; ks += 2) {
-        stage_load();                      // step ks+1
-        compute(0, 0);
-        stage_write(A_BUF, B_BUF);
+    for (; ks + 1 < S; ks += 2) {
+        if (ks + 2 < S) stage_load(raA, rbA);      // step ks+2 -> set A
+        compute(0, 0);                             // step ks   (buffer 0)
+        stage_write(raB, rbB, A_BUF, B_BUF);       // step ks+1 -> buffer 1
         __syncthreads();
-        const bool more = ks + 2 < mg.steps;
-        if (more) stage_load();            // step ks+2
-        compute(A_BUF, B_BUF);
-        if (more) stage_write(0, 0);
+        if (ks + 3 < S) stage_load(raB, rbB);      // step ks+3 -> set B
+        compute(A_BUF, B_BUF);                     // step ks+1 (buffer 1)
+        if (ks + 2 < S) stage_write(raA, rbA, 0, 0);   // step ks+2 -> buffer 0
         __syncthreads();
     }
-    if (ks < mg.steps) compute(0, 0);      // odd step count: last step sits in buffer 0
+    if (ks < S) compute(0, 0);                     // odd step count: last step sits in buffer 0
 
     // ---- epilogue -------------------------------------------------------------------
 #pragma unroll
