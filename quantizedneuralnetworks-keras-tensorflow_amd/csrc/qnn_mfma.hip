@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(MfmaGeom mg, EpiA
     uint4 raA[NA], rbA[NB], raB[NA], rbB[NB];     // two staging register sets (2-deep prefetch)
     auto stage_load = [&](uint4 (&ra)[NA], uint4 (&rb)[NB]) {
         const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
-        const int woff = s_tap * g.cin + s_kc * 64;
+        const int woff = s_tap < g.kh * g.kw ? s_tap * g.cin + s_kc * 64 : (int)0x40000000;   // past the end -> zeros
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             const bool ok = (a_mask[p] >> s_tap) & 1u;
@@ -337,20 +337,23 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(MfmaGeom mg, EpiA
 
     // ---- main loop: one barrier per K-step; the loads of step k+2 are issued before the
     // MFMAs of step k and only waited for (counted vmcnt) after the MFMAs of step k+1 ----
+    // Loads are issued UNCONDITIONALLY (a step past the end has tap >= kh*kw, whose mask
+    // bit is 0 -> out-of-range offset -> the buffer load returns zeros without touching
+    // memory): conditional loads make the compiler fall back to vmcnt(0).
     const int S = mg.steps;
     stage_load(raA, rbA);                          // step 0
-    if (S > 1) stage_load(raB, rbB);               // step 1
+    stage_load(raB, rbB);                          // step 1
     stage_write(raA, rbA, 0, 0);
     __syncthreads();
     int ks = 0;
     for (; ks + 1 < S; ks += 2) {
-        if (ks + 2 < S) stage_load(raA, rbA);      // step ks+2 -> set A
+        stage_load(raA, rbA);                      // step ks+2 -> set A
         compute(0, 0);                             // step ks   (buffer 0)
         stage_write(raB, rbB, A_BUF, B_BUF);       // step ks+1 -> buffer 1
         __syncthreads();
-        if (ks + 3 < S) stage_load(raB, rbB);      // step ks+3 -> set B
+        stage_load(raB, rbB);                      // step ks+3 -> set B
         compute(A_BUF, B_BUF);                     // step ks+1 (buffer 1)
-        if (ks + 2 < S) stage_write(raA, rbA, 0, 0);   // step ks+2 -> buffer 0
+        stage_write(raA, rbA, 0, 0);               // step ks+2 -> buffer 0
         __syncthreads();
     }
     if (ks < S) compute(0, 0);                     // odd step count: last step sits in buffer 0
