@@ -20,6 +20,8 @@
 // minor": rows 4g..4g+3 of the tile are one window and land in four consecutive
 // accumulator registers of ONE lane (C/D layout row = (r&3) + 8*(r>>2) + 4*(lane>>5)),
 // so pooling is an in-lane max -- no cross-lane traffic.
+#include <type_traits>
+
 #include "qnn_common.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -278,21 +280,22 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(MfmaGeom mg, EpiA
 
     // uniform K-step state, advanced incrementally (no divisions in the loop)
     int s_tap = 0, s_kc = 0, s_dy = 0, s_dx = 0;
-    uint4 raA[NA], rbA[NB], raB[NA], rbB[NB];     // two staging register sets (2-deep prefetch)
-    auto stage_load = [&](uint4 (&ra)[NA], uint4 (&rb)[NB]) {
+    // two staging register sets (2-deep prefetch); int4 activations stay packed (8 B per
+    // 16-channel chunk) until they are written to LDS
+    using araw_t = typename std::conditional<XS == QNN_STORE_I8, uint4, uint2>::type;
+    araw_t raA[NA], raB[NA];
+    uint4 rbA[NB], rbB[NB];
+    auto stage_load = [&](araw_t (&ra)[NA], uint4 (&rb)[NB]) {
         const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
         const int woff = s_tap < g.kh * g.kw ? s_tap * g.cin + s_kc * 64 : (int)0x40000000;   // past the end -> zeros
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             const bool ok = (a_mask[p] >> s_tap) & 1u;
             const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;   // out of range -> zeros
-            if constexpr (XS == QNN_STORE_I8) {
+            if constexpr (XS == QNN_STORE_I8)
                 ra[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
-            } else {
-                const uint2 v = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0));
-                ra[p] = make_uint4((v.x << 4) & 0xF0F0F0F0u, v.x & 0xF0F0F0F0u,
-                                   (v.y << 4) & 0xF0F0F0F0u, v.y & 0xF0F0F0F0u);
-            }
+            else
+                ra[p] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0));
         }
 #pragma unroll
         for (int p = 0; p < NB; ++p)
@@ -312,9 +315,15 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(MfmaGeom mg, EpiA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
 
-    auto stage_write = [&](const uint4 (&ra)[NA], const uint4 (&rb)[NB], int bufoff_a, int bufoff_b) {
+    auto stage_write = [&](const araw_t (&ra)[NA], const uint4 (&rb)[NB], int bufoff_a, int bufoff_b) {
 #pragma unroll
-        for (int p = 0; p < NA; ++p) *reinterpret_cast<uint4*>(smem + a_lds[p] + bufoff_a) = ra[p];
+        for (int p = 0; p < NA; ++p) {
+            uint4 v;
+            if constexpr (XS == QNN_STORE_I8) v = ra[p];
+            else v = make_uint4((ra[p].x << 4) & 0xF0F0F0F0u, ra[p].x & 0xF0F0F0F0u,
+                                (ra[p].y << 4) & 0xF0F0F0F0u, ra[p].y & 0xF0F0F0F0u);
+            *reinterpret_cast<uint4*>(smem + a_lds[p] + bufoff_a) = v;
+        }
 #pragma unroll
         for (int p = 0; p < NB; ++p) *reinterpret_cast<uint4*>(smem + b_lds[p] + bufoff_b) = rb[p];
     };
