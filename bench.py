@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 
 PKG = "quantizedneuralnetworks-keras-tensorflow_amd"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "i8": 5000.0}   # dense matrix peaks (f32: spec; i8: ~5 POP/s dense)
 BATCH = 4096
 WORKLOADS = {
     "vgg64_full_qnn_w4a4": 2,   # BASELINE.json configs[2]: the config the metric is quoted on
@@ -173,21 +174,52 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * N * args.steps / dt
         d = per_kernel[dom]
-        achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        hbm_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                prefix = ("k_conv_first_mfma" if d["kernel"].startswith("mfma_f32_first") else
+                          "k_conv_mfma" if d["kernel"].startswith("mfma_i") else
+                          "k_conv_ps" if d["kernel"].startswith("ps_") else
+                          "k_dense_packed" if d["kernel"].startswith("dense_") else "k_conv_generic")
+                cands = [v for k, v in tj.items() if k.startswith(prefix)]
+                ent = cands[0] if len(cands) == 1 else {}
+                if ent:
+                    # rocprofv3 FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE counts 64 of every
+                    # 128 fetched bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled
+                    traffic = (2.0 * ent.get("fetch_kb", 0.0) + ent.get("write_kb", 0.0)) * 1024.0
+            except Exception:
+                traffic = None
+        if d["kernel"].startswith("mfma_"):
+            kind = "f32" if d["kernel"].startswith("mfma_f32") else "i8"
+            achieved = 2.0 * d["macs"] / (d["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": d["kernel"], "layer_index": dom, "achieved": achieved,
+                    "peak": MFMA_PEAK_TFLOPS[kind], "unit": "TFLOP/s",
+                    "frac": achieved / MFMA_PEAK_TFLOPS[kind], "traffic": traffic,
+                    "mfma_dtype": kind, "algorithmic_flops_per_launch": 2.0 * d["macs"],
+                    "algorithmic_bytes_per_launch": d["bytes"], "avg_launch_ms": d["ms"],
+                    "hbm_GBps": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS}
+        else:
+            roof = {"bound": "hbm", "kernel": d["kernel"], "layer_index": dom, "achieved": hbm_gbs,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": d["bytes"], "avg_launch_ms": d["ms"],
+                    "note": "VALU-bound packed kernel; see kernels[].TMACps and DESIGN.md"}
+        m0_bytes = {1: 442408, 2: 442408, 3: 7237672}[idx]     # SURVEY.md 8d, float32-surface traffic per image
         out = {
             "metric": "images/sec @ batch 4096, CIFAR-10 VGG full-qnn 4/4; % HBM roofline",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {1: "u1 xnor/popcount", 2: "int4", 3: "int8"}[idx],
+            "scaling": "weak", "vs_baseline": None, "dtype": {1: "u1", 2: "int4", 3: "int8"}[idx],
             "data": "synthetic",
             "config": {"workload": args.workload, "batch_per_gpu": N, "global_batch": N * world,
-                       "traffic_model": "M1 (packed inter-layer tensors)", "engine": "FusedModel", "conv_impl": args.impl,
-                       "hipgraph": graph is not None, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": d["kernel"], "layer_index": dom,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": d["bytes"], "avg_launch_ms": d["ms"],
-                         "note": "fused packed kernels are VALU-bound (dot8/popcount), see DESIGN.md"},
+                       "traffic_model": "M1 (packed inter-layer tensors)", "engine": "FusedModel",
+                       "conv_impl": args.impl, "hipgraph": graph is not None, "parallelism": "dp%d" % world,
+                       # the metric's "% HBM roofline" in BASELINE.md's sense: float32-surface (M0) bytes
+                       # per image x images/s over 8 TB/s (the fused engine does not move those bytes)
+                       "pct_of_m0_hbm_roofline": 100.0 * value / world * m0_bytes / (HBM_PEAK_GBS * 1e9)},
+            "roofline": roof,
             "kernels": [{"kernel": k["kernel"], "ms": round(k["ms"], 5),
                          "GBps": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 2),
                          "TMACps": round(k["macs"] / (k["ms"] * 1e-3) / 1e12, 3)} for k in per_kernel],

@@ -20,6 +20,9 @@
 // minor": rows 4g..4g+3 of the tile are one window and land in four consecutive
 // accumulator registers of ONE lane (C/D layout row = (r&3) + 8*(r>>2) + 4*(lane>>5)),
 // so pooling is an in-lane max -- no cross-lane traffic.
+#include <stdlib.h>
+#include <string.h>
+
 #include <type_traits>
 
 #include "qnn_common.h"
@@ -38,6 +41,7 @@ struct MfmaGeom {
     int x_pix_bytes;   // bytes per input pixel as stored
     long total_q;      // stored output pixels
     uint32_t x_bytes, w_bytes;   // sizes of the x tensor / int8 weight image (buffer descriptors)
+    int ablate;                  // timing experiments only (QNN_MFMA_ABLATE): 1 = no A traffic, 2 = no B traffic
 };
 
 // ---------------------------------------------------------------------------------
@@ -199,7 +203,7 @@ __device__ __forceinline__ void store_values(const float (&t)[NV], const LaneEpi
 
 // XS: QNN_STORE_I8 or QNN_STORE_I4 (storage of x; weights are always int8 bytes here)
 template <int XS, int WM, int WN, int OUT, int POOL>
-__global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(MfmaGeom mg, EpiArgs e,
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2 : 3)) void k_conv_mfma(MfmaGeom mg, EpiArgs e,
                                                            const uint8_t* __restrict__ x,
                                                            const uint8_t* __restrict__ wq8,
                                                            void* __restrict__ y) {
@@ -287,10 +291,11 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void k_conv_mfma(MfmaGeom mg, EpiA
     uint4 rbA[NB], rbB[NB];
     auto stage_load = [&](araw_t (&ra)[NA], uint4 (&rb)[NB]) {
         const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
-        const int woff = s_tap < g.kh * g.kw ? s_tap * g.cin + s_kc * 64 : (int)0x40000000;   // past the end -> zeros
+        const int woff = (s_tap < g.kh * g.kw && !(mg.ablate & 2)) ? s_tap * g.cin + s_kc * 64
+                                                                    : (int)0x40000000;   // past the end -> zeros
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
-            const bool ok = (a_mask[p] >> s_tap) & 1u;
+            const bool ok = ((a_mask[p] >> s_tap) & 1u) && !(mg.ablate & 1);
             const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;   // out of range -> zeros
             if constexpr (XS == QNN_STORE_I8)
                 ra[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
@@ -656,16 +661,26 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     if (xb >= 2.0e9 || wb >= 2.0e9) return 1;          // 31-bit buffer offsets
     mg.x_bytes = (uint32_t)xb;
     mg.w_bytes = (uint32_t)wb;
+    static const int ablate = getenv("QNN_MFMA_ABLATE") ? atoi(getenv("QNN_MFMA_ABLATE")) : 0;
+    mg.ablate = ablate;
     EpiArgs e2 = e;
     if (x_store == QNN_STORE_I4) e2.scale = e.scale * (1.0f / 256.0f);   // both operands carry *16
-    const bool wide = (g.cout % 128) == 0;
-    snprintf(name, name_len, "mfma_%s_%s", x_store == QNN_STORE_I8 ? "i8" : "i4", wide ? "128x128" : "256x64");
-    int rc;
-    if (x_store == QNN_STORE_I8)
-        rc = wide ? launch_out<QNN_STORE_I8, 2, 2>(mg, e2, x, w->d_mfma, y, s)
-                  : launch_out<QNN_STORE_I8, 4, 1>(mg, e2, x, w->d_mfma, y, s);
-    else
-        rc = wide ? launch_out<QNN_STORE_I4, 2, 2>(mg, e2, x, w->d_mfma, y, s)
-                  : launch_out<QNN_STORE_I4, 4, 1>(mg, e2, x, w->d_mfma, y, s);
-    return rc;
+    // tile shape: waves along M x waves along N (64x64 per wave)
+    static const char* tile_env = getenv("QNN_MFMA_TILE");
+    int wm_ = 4, wn_ = 1;
+    if ((g.cout % 256) == 0) { wm_ = 4; wn_ = 4; }          // measured: 256x256 > 128x256 > 256x128 > 128x128
+    else if ((g.cout % 128) == 0) { wm_ = 4; wn_ = 2; }
+    if (tile_env && strlen(tile_env) == 3) {
+        const int em = tile_env[0] - '0', en = tile_env[2] - '0';
+        if (em >= 1 && en >= 1 && (g.cout % (64 * en)) == 0) { wm_ = em; wn_ = en; }
+    }
+    snprintf(name, name_len, "mfma_%s_%dx%d", x_store == QNN_STORE_I8 ? "i8" : "i4", 64 * wm_, 64 * wn_);
+#define TILE_CASE(XS_, M_, N_) \
+    if (x_store == XS_ && wm_ == M_ && wn_ == N_) return launch_out<XS_, M_, N_>(mg, e2, x, w->d_mfma, y, s);
+    TILE_CASE(QNN_STORE_I8, 4, 1) TILE_CASE(QNN_STORE_I8, 2, 2) TILE_CASE(QNN_STORE_I8, 4, 2)
+    TILE_CASE(QNN_STORE_I8, 2, 4) TILE_CASE(QNN_STORE_I8, 4, 4)
+    TILE_CASE(QNN_STORE_I4, 4, 1) TILE_CASE(QNN_STORE_I4, 2, 2) TILE_CASE(QNN_STORE_I4, 4, 2)
+    TILE_CASE(QNN_STORE_I4, 2, 4) TILE_CASE(QNN_STORE_I4, 4, 4)
+#undef TILE_CASE
+    return 1;
 }

@@ -40,5 +40,21 @@ def main(root):
                 print("%-72s n=%d %s" % (k, len(next(iter(cs.values()))), " ".join(parts)))
 
 
+def traffic_json(root, out_path):
+    """Per-kernel average FETCH_SIZE / WRITE_SIZE (KiB per dispatch) keyed by template name."""
+    import json
+    res = {}
+    for sub, key in (("pmc_fetch", "fetch_kb"), ("pmc_write", "write_kb")):
+        for f in find(os.path.join(root, sub), "counter_collection.csv"):
+            agg = defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+            for k, v in agg.items():
+                res.setdefault(k, {})[key] = sum(v) / len(v)
+    json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    if len(sys.argv) > 2:
+        traffic_json(sys.argv[1], sys.argv[2])
