@@ -156,6 +156,19 @@ int qnn_conv2d_forward(const qnn_weights_t* w, const void* x, int x_store, int x
                        int N, int H, int W, const qnn_epilogue_t* epi, void* y,
                        void* stream);
 /*
+ * The same layer behind the Keras float32 surface with the PRECEDING activation layer
+ * fused on load: y = conv2d(in_fn(x), W) (+ epilogue).  x is float32 NHWC; in_fn is
+ * QNN_FN_BINARY_TANH (models/model_factory.py:47: Activation(binary_tanh)),
+ * QNN_FN_QUANTIZED_TANH with in_bits = abits (model_factory.py:36), or QNN_FN_GRID when x
+ * already holds grid values.  The weights must have been prepacked for a packed store.
+ * `workspace` is DEVICE scratch of qnn_conv2d_workspace_bytes() bytes; it is only used
+ * when no single fused kernel covers the shape (then: clip+pack pass, conv pass).
+ */
+size_t qnn_conv2d_workspace_bytes(const qnn_weights_t* w, int N, int H, int W);
+int qnn_conv2d_forward_f32in(const qnn_weights_t* w, const float* x, int in_fn, int in_bits,
+                             int N, int H, int W, const qnn_epilogue_t* epi, void* y,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/*
  * BinaryDense.call (layers/binary_layers.py:78-85) / QuantizedDense.call
  * (layers/quantized_layers.py:79-88): x (N, in) float32 or packed -> y (N, units).
  * pool must be 1.

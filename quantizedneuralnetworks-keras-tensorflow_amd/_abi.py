@@ -22,7 +22,7 @@ EXPORTS = [
     "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
     "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32",
     "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant",
-    "qnn_conv2d_forward", "qnn_dense_forward",
+    "qnn_conv2d_forward", "qnn_dense_forward", "qnn_conv2d_forward_f32in", "qnn_conv2d_workspace_bytes",
 ]
 
 
@@ -72,6 +72,10 @@ def load():
     lib.qnn_weights_dequant.argtypes = [vp, vp, vp]
     lib.qnn_conv2d_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
     lib.qnn_dense_forward.argtypes = [vp, vp, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
+    lib.qnn_conv2d_workspace_bytes.argtypes = [vp, ci, ci, ci]
+    lib.qnn_conv2d_workspace_bytes.restype = sz
+    lib.qnn_conv2d_forward_f32in.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue), vp,
+                                             vp, sz, vp]
     for name in EXPORTS:   # every symbol the header declares must be exported
         getattr(lib, name)
     _lib = lib
@@ -210,6 +214,27 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
     epi = Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store)
     check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
                                     ptr(y), stream_ptr()), "qnn_conv2d_forward")
+    return y, Ho, Wo
+
+
+def conv2d_f32in(w, x, in_fn, in_bits, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0, pool=1,
+                 out_store=STORE_F32):
+    """qnn_conv2d_forward_f32in: float32 NHWC x, activation clip `in_fn` fused on load."""
+    x = require_cuda(x, "conv2d_f32in")
+    N, H, W, _ = x.shape
+    kh, kw, cin, cout = w.shape
+    Ho = out_hw(H, kh, w.stride, w.same_pad) // pool
+    Wo = out_hw(W, kw, w.stride, w.same_pad) // pool
+    if out_store == STORE_F32:
+        y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty((N * Ho * Wo, words(out_store, cout)), dtype=torch.int32, device=x.device)
+    need = load().qnn_conv2d_workspace_bytes(w.handle, N, H, W)
+    ws = torch.empty((max(need, 4) + 3) // 4, dtype=torch.int32, device=x.device)
+    epi = Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store)
+    check(load().qnn_conv2d_forward_f32in(w.handle, ptr(x), in_fn, in_bits, N, H, W, ctypes.byref(epi),
+                                          ptr(y), ptr(ws), ws.numel() * 4, stream_ptr()),
+          "qnn_conv2d_forward_f32in")
     return y, Ho, Wo
 
 

@@ -391,6 +391,118 @@ int launch_dense(const void* x, const qnn_weights* w, const EpiArgs& e, void* y,
 }
 
 // ---------------------------------------------------------------------------
+// Layer-surface 1-bit conv (traffic model M0): float32 NHWC in, float32 NHWC out,
+// BinaryConv2D.call (binary_layers.py:160-187) with the preceding binary_tanh
+// (binary_ops.py:37-51) fused on load.  One workgroup owns a strip of rows of one image:
+//   phase 1  all waves stream the strip's float32 input (lane = channel: a 256-byte
+//            coalesced load per 64 channels), compare against 2^-24 and the wave's
+//            64-bit lane mask -- which IS the packed pixel -- goes to LDS;
+//   phase 2  lane = output channel with its whole 3x3xCin filter resident in VGPRs; the
+//            wave walks its pixels (wave-uniform), reads each tap's words from LDS with
+//            a broadcast ds_read, XNOR+popcounts, and stores 64 channels = 256 contiguous
+//            bytes per pixel.  Out-of-image taps are skipped by uniform branches, so no
+//            correction table is needed here.
+// ---------------------------------------------------------------------------
+template <int CW>   // packed words per pixel (cin / 32), even
+__global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e, int in_fn, int TR,
+                                                          int strips, const float* __restrict__ x,
+                                                          const uint32_t* __restrict__ wp,
+                                                          float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    uint2* tile = reinterpret_cast<uint2*>(smem_x);            // [(TR+2) rows][W][CW/2] uint2
+    constexpr int PAIRS = CW / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x / strips;
+    const int r0 = (blockIdx.x - n * strips) * TR;               // first output row of the strip
+    const int rows_out = min(TR, g.H - r0);
+    const int cbase = blockIdx.y * 64;
+    const float thr = (in_fn == QNN_FN_GRID) ? 0.0f : 0x1p-24f;  // binary_tanh(x) = +1 iff x > 2^-24
+
+    // ---- phase 1: binarize rows r0-1 .. r0+rows_out into LDS ----
+    const int row_lo = max(r0 - 1, 0), row_hi = min(r0 + rows_out, g.H - 1);   // inclusive, in-image
+    const int groups = (row_hi - row_lo + 1) * g.W * PAIRS;     // 64-channel groups to convert
+    const float* xin = x + ((size_t)n * g.H + row_lo) * g.W * g.cin;
+    uint2* tdst = tile + (size_t)(row_lo - (r0 - 1)) * g.W * PAIRS;
+    constexpr int U = 4;
+    for (int gi = wave * U; gi < groups; gi += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (gi + u < groups) ? xin[(size_t)(gi + u) * 64 + lane] : -1.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long m = __ballot(v[u] > thr);
+            if (lane == u && gi + u < groups) tdst[gi + u] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+        }
+    }
+    // ---- this lane's filter ----
+    uint32_t wreg[9 * CW];
+    const uint32_t* wsrc = wp + (size_t)(cbase + lane) * (9 * CW);
+#pragma unroll
+    for (int k = 0; k < 9 * CW; ++k) wreg[k] = wsrc[k];
+    const int c = cbase + lane;
+    const float bias = e.bias ? e.bias[c] : 0.0f;
+    const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
+    const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+    __syncthreads();
+
+    // ---- phase 2: the wave walks its pixels ----
+    const int npix = rows_out * g.W;
+    float* yout = y + (((size_t)n * g.H + r0) * g.W) * g.cout + c;
+    for (int p = wave; p < npix; p += 4) {
+        const int oy = p / g.W, ox = p - oy * g.W;              // uniform; row inside the strip
+        const int gy = r0 + oy;
+        int acc = 0, nvalid = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = gy + dy - 1;
+            if ((unsigned)iy >= (unsigned)g.H) continue;         // wave-uniform
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox + dx - 1;
+                if ((unsigned)ix >= (unsigned)g.W) continue;     // wave-uniform
+                const uint2* a = tile + ((size_t)(oy + dy) * g.W + ix) * PAIRS;   // same address in all lanes
+#pragma unroll
+                for (int j = 0; j < PAIRS; ++j) {
+                    const uint2 av = a[j];
+                    acc += __popc(av.x ^ wreg[(dy * 3 + dx) * CW + 2 * j]);
+                    acc += __popc(av.y ^ wreg[(dy * 3 + dx) * CW + 2 * j + 1]);
+                }
+                ++nvalid;
+            }
+        }
+        float v = (float)(nvalid * g.cin - 2 * acc);
+        v = __fadd_rn(v, bias);
+        v = __fadd_rn(__fmul_rn(v, inv), shift);
+        if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
+        else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
+        yout[(size_t)p * g.cout] = v;
+    }
+}
+
+// returns 0 if launched
+int try_launch_xnor_f32(const ConvGeom& g, const EpiArgs& e, int in_fn, const float* x,
+                        const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len) {
+    if (w->store != QNN_STORE_BIN || !w->d_packed) return 1;
+    if (g.kh != 3 || g.kw != 3 || g.stride != 1 || !w->same_pad || g.pool != 1) return 1;
+    if (g.cin % 64 != 0 || g.cout % 64 != 0 || e.out_store != QNN_STORE_F32) return 1;
+    if (in_fn != QNN_FN_BINARY_TANH && in_fn != QNN_FN_GRID) return 1;
+    const int cw = g.cin / 32;
+    if (cw != 2 && cw != 4 && cw != 8) return 1;
+    // strip height: whole image if it fits in ~32 KB of LDS, else as many rows as fit
+    int TR = g.H;
+    while ((size_t)(TR + 2) * g.W * cw * 4 > 32768 && TR > 1) TR = (TR + 1) / 2;
+    const int strips = (g.H + TR - 1) / TR;
+    const size_t lds = (size_t)(TR + 2) * g.W * cw * 4;
+    const dim3 grid((unsigned)(g.N * strips), (unsigned)(g.cout / 64)), block(kBlock);
+    snprintf(name, name_len, "xnor_f32_cw%d", cw);
+    if (cw == 2) hipLaunchKernelGGL(k_conv_xnor_f32<2>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
+    else if (cw == 4) hipLaunchKernelGGL(k_conv_xnor_f32<4>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
+    else hipLaunchKernelGGL(k_conv_xnor_f32<8>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------
 template <int XS, int CW, int K>
@@ -698,6 +810,50 @@ extern "C" int qnn_conv2d_forward(const qnn_weights_t* w, const void* x, int x_s
                                   int N, int H, int W, const qnn_epilogue_t* epi, void* y,
                                   void* stream) {
     return conv_forward(w, x, x_store, x_bits, N, H, W, epi, y, stream, false);
+}
+
+// float32 NHWC input with the preceding activation clip fused on load.  `workspace`
+// (qnn_conv2d_workspace_bytes) is only touched when no fused kernel fits and the clip +
+// pack has to run as a separate pass.
+extern "C" size_t qnn_conv2d_workspace_bytes(const qnn_weights_t* w, int N, int H, int W) {
+    if (!w || w->store == QNN_STORE_F32) return 0;
+    return (size_t)N * H * W * w->cw * 4;
+}
+
+extern "C" int qnn_conv2d_forward_f32in(const qnn_weights_t* w, const float* x, int in_fn, int in_bits,
+                                        int N, int H, int W, const qnn_epilogue_t* epi, void* y,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    QNN_REQUIRE(w && x && y && epi, QNN_EINVAL, "qnn_conv2d_forward_f32in: null pointer");
+    QNN_REQUIRE(w->store != QNN_STORE_F32, QNN_EINVAL,
+                "qnn_conv2d_forward_f32in: weights were prepacked for float32 inputs only");
+    QNN_REQUIRE(in_fn == QNN_FN_BINARY_TANH || in_fn == QNN_FN_QUANTIZED_TANH || in_fn == QNN_FN_GRID,
+                QNN_EINVAL, "qnn_conv2d_forward_f32in: in_fn=%d", in_fn);
+    const int x_bits = w->store == QNN_STORE_BIN ? 1 : in_bits;
+    if (w->store == QNN_STORE_BIN && epi->out_store == QNN_STORE_F32 && epi->pool == 1 && N > 0 &&
+        qnn_conv_impl_pref() != 2) {
+        ConvGeom g;
+        g.N = N; g.H = H; g.W = W;
+        g.cin = w->cin; g.cout = w->cout; g.kh = w->kh; g.kw = w->kw; g.stride = w->stride;
+        qnn_same_pad(H, w->kh, w->stride, w->same_pad, &g.Ho, &g.pt);
+        qnn_same_pad(W, w->kw, w->stride, w->same_pad, &g.Wo, &g.pl);
+        g.cw = w->cw; g.kwords = w->kwords; g.pool = 1; g.Hp = g.Ho; g.Wp = g.Wo;
+        g.fd_wp = qnn_fastdiv((uint32_t)g.Wp); g.fd_hp = qnn_fastdiv((uint32_t)g.Hp);
+        EpiArgs e;
+        int rc = check_epilogue(w, epi, 0, &e);
+        if (rc != QNN_OK) return rc;
+        char name[64];
+        if (try_launch_xnor_f32(g, e, in_fn, x, w, y, (hipStream_t)stream, name, sizeof(name)) == 0) {
+            qnn_set_kernel_name(name);
+            QNN_HIP(hipGetLastError());
+            return QNN_OK;
+        }
+    }
+    const size_t need = qnn_conv2d_workspace_bytes(w, N, H, W);
+    QNN_REQUIRE(workspace && workspace_bytes >= need, QNN_EINVAL,
+                "qnn_conv2d_forward_f32in: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    int rc = qnn_pack_f32(x, workspace, (size_t)N * H * W, w->cin, in_fn, x_bits, w->store, stream);
+    if (rc != QNN_OK) return rc;
+    return conv_forward(w, workspace, w->store, x_bits, N, H, W, epi, y, stream, false);
 }
 
 extern "C" int qnn_dense_forward(const qnn_weights_t* w, const void* x, int x_store, int x_bits,

@@ -128,6 +128,44 @@ __global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ x,
     }
 }
 
+// BIN pack, channels % 32 == 0: the packed bit index equals the flat element index, so
+// lane = element: one coalesced dword load per lane, one compare, and the wave's 64-bit
+// lane mask IS two packed words (v_cmp writes it straight into an SGPR pair).  Eight
+// loads are kept in flight per lane to cover HBM latency.
+__global__ __launch_bounds__(kBlock) void k_pack_bin_ballot(const float* __restrict__ x,
+                                                            uint32_t* __restrict__ y, size_t n,
+                                                            int fn) {
+    constexpr int U = 8;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+    const size_t chunks = n / (64 * U);          // full chunks of U*64 elements
+    const float thr = (fn == QNN_FN_GRID) ? 0.0f : 0x1p-24f;   // binary_tanh(x) = +1 iff x > 2^-24
+    for (size_t c = wave; c < chunks; c += nwaves) {
+        const float* src = x + c * (64 * U) + lane;
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[u * 64];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long m = __ballot(v[u] > thr);
+            if (lane == 2 * u) mine = (uint32_t)m;
+            if (lane == 2 * u + 1) mine = (uint32_t)(m >> 32);
+        }
+        if (lane < 2 * U) y[c * (2 * U) + lane] = mine;
+    }
+    // tail: remaining (< U*64) elements, 64 at a time, by the first wave
+    if (wave == 0) {
+        for (size_t i = chunks * (64 * U); i < n; i += 64) {
+            const float val = (i + lane < n) ? x[i + lane] : -1.0f;
+            const unsigned long long m = __ballot(val > thr);
+            if (lane == 0) y[i / 32] = (uint32_t)m;
+            if (lane == 1 && i + 32 < n) y[i / 32 + 1] = (uint32_t)(m >> 32);
+        }
+    }
+}
+
 template <int STORE>
 __global__ __launch_bounds__(kBlock) void k_unpack(const uint32_t* __restrict__ x,
                                                    float* __restrict__ y, size_t pixels,
@@ -220,7 +258,10 @@ extern "C" int qnn_pack_f32(const float* x, void* y, size_t pixels, int channels
     }
     hipStream_t s = (hipStream_t)stream;
     const int g = grid_for(words);
-    if (store == QNN_STORE_BIN)
+    if (store == QNN_STORE_BIN && (channels % 32) == 0)
+        hipLaunchKernelGGL(k_pack_bin_ballot, dim3(grid_for(pixels * (size_t)channels / 8)), dim3(kBlock),
+                           0, s, x, (uint32_t*)y, pixels * (size_t)channels, fn);
+    else if (store == QNN_STORE_BIN)
         hipLaunchKernelGGL(k_pack<QNN_STORE_BIN>, dim3(g), dim3(kBlock), 0, s, x, (uint32_t*)y,
                            pixels, channels, cw, fn, m);
     else if (store == QNN_STORE_I4)

@@ -269,12 +269,13 @@ class GraphModel:
                     store = _join_store(bits, wstore)
                     pre = src.pre
                     C = pre.shape[-1]
-                    xp = _abi.pack(pre, C, src.fn, src.nb if src.fn == _abi.FN_QUANTIZED_TANH else 1, store)
                     w = self._get_weights(i, op, store)
+                    nb_in = src.nb if src.fn == _abi.FN_QUANTIZED_TANH else 1
                     if kind == "conv":
-                        N, H, W, _ = pre.shape
-                        y, _, _ = _abi.conv2d(w, xp, store, bits, N, H, W, inv, shift)
+                        # activation clip fused on load, BN fused in the epilogue
+                        y, _, _ = _abi.conv2d_f32in(w, pre, src.fn, nb_in, inv, shift)
                     else:
+                        xp = _abi.pack(pre, C, src.fn, nb_in, store)
                         y = _abi.dense(w, xp, store, bits, pre.shape[0], inv, shift)
                 else:
                     xin = self._plain(src)

@@ -284,8 +284,7 @@ class LowBitConv2D(LowBitLayer):
             y, _, _ = _abi.conv2d(self._weights(_abi.STORE_F32), x, _abi.STORE_F32, 0, N, H, W)
         else:
             store, bits, fn, nb = plan
-            xp = _abi.pack(x, C, fn, nb, store)
-            y, _, _ = _abi.conv2d(self._weights(store), xp, store, bits, N, H, W)
+            y, _, _ = _abi.conv2d_f32in(self._weights(store), x, fn, nb)
         if self.activation is not None:
             y = self.activation(y)
         return y

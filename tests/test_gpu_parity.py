@@ -311,6 +311,38 @@ def test_float_input_layer(case, pool, impl):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64), (2, 8, 8, 64, 64), (2, 5, 7, 128, 64),
+                                   (1, 32, 32, 256, 128), (2, 40, 24, 64, 192), (1, 3, 3, 64, 64)])
+@pytest.mark.parametrize("with_bn", [False, True])
+def test_layer_surface_xnor_fused(shape, with_bn):
+    """float32 in -> binary_tanh on load -> XNOR conv -> float32 out in ONE kernel (M0 path)."""
+    N, H, W, C, Cout = shape
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
+    pre = rng.standard_normal((N, H, W, C)).astype(F32)
+    pre.reshape(-1)[:7] = [0.0, 2.0 ** -24, 2.0 ** -23, -0.0, 1e-30, -1e-30, 1.0]   # threshold edge cases
+    op = {"op": "conv", "kind": "binary", "kernel": rng.uniform(-1, 1, (3, 3, C, Cout)).astype(F32),
+          "bias": (rng.standard_normal(Cout) * 0.05).astype(F32), "strides": (1, 1), "padding": "same"}
+    bn = _rand_bn(rng, Cout, 9.0 * C) if with_bn else None
+    w = engine._prepack(op, _abi.STORE_BIN, torch.device("cuda"))
+    inv = shift = None
+    if bn is not None:
+        i, s_ = engine.bn_constants(bn)
+        inv, shift = dev(i), dev(s_)
+    _abi.set_conv_impl(_abi.IMPL_AUTO)
+    y, _, _ = _abi.conv2d_f32in(w, dev(pre), _abi.FN_BINARY_TANH, 1, inv, shift)
+    assert _abi.last_kernel().startswith("xnor_f32_cw")
+    spec = [BIN_ACT, dict(op)] + ([bn] if bn is not None else [])
+    np.testing.assert_array_equal(host(y), O.run_spec(spec, pre))
+    # grid input (values already +-1) and the two-pass fallback agree with it
+    xb = O.binary_tanh(pre)
+    y2, _, _ = _abi.conv2d_f32in(w, dev(xb), _abi.FN_GRID, 1, inv, shift)
+    assert torch.equal(y, y2)
+    _abi.set_conv_impl(_abi.IMPL_MFMA)       # disables the fused kernel -> pack + conv
+    y3, _, _ = _abi.conv2d_f32in(w, dev(pre), _abi.FN_BINARY_TANH, 1, inv, shift)
+    _abi.set_conv_impl(_abi.IMPL_AUTO)
+    assert torch.equal(y, y3)
+
+
 @pytest.mark.parametrize("kind,nb,in_act", [("binary", None, BIN_ACT), ("quantized", 4, Q(4)),
                                             ("quantized", 8, Q(8)), ("quantized", 4, None)])
 def test_dense_layer(kind, nb, in_act):

@@ -56,6 +56,8 @@ def main():
         t_pack = timeit(lambda: abi.pack(x, C, fn, nb, store))
         t_conv = timeit(lambda: abi.conv2d(w, xp, store, bits, n, H, H))
         kern = abi.last_kernel()
+        t_fused = timeit(lambda: abi.conv2d_f32in(w, x, fn, nb))
+        kern_fused = abi.last_kernel()
         in_b, out_b = n * H * H * C * 4, n * H * H * Cout * 4
         pk_b = xp.numel() * 4
         macs = n * H * H * 9 * C * Cout
@@ -68,7 +70,10 @@ def main():
             "layer_ms": round(t_pack + t_conv, 4),
             "m0_GBps": round((in_b + out_b) / (t_pack + t_conv) / 1e6, 1),
             "m0_hbm_frac": round((in_b + out_b) / (t_pack + t_conv) / 1e6 / HBM, 3),
-            "TMACps": round(macs / t_conv / 1e9, 1)})
+            "TMACps": round(macs / t_conv / 1e9, 1),
+            "f32in_kernel": kern_fused, "f32in_ms": round(t_fused, 4),
+            "f32in_m0_GBps": round((in_b + out_b) / t_fused / 1e6, 1),
+            "f32in_m0_hbm_frac": round((in_b + out_b) / t_fused / 1e6 / HBM, 3)})
         print(json.dumps(rows[-1]))
     abi.set_conv_impl(abi.IMPL_AUTO)
     # elementwise clips (float32 -> float32)
