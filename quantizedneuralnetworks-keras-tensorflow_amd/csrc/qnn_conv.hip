@@ -18,6 +18,8 @@
 //                   packed outputs are assembled in a register and stored once.
 //   k_conv_generic  one thread per stored output element/word, runtime loops; any
 //                   shape, any stride, float32 inputs; the correctness fallback.
+#include <type_traits>
+
 #include "qnn_common.h"
 
 namespace {
@@ -446,37 +448,59 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
     const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
     __syncthreads();
 
-    // ---- phase 2: the wave walks its pixels ----
-    const int npix = rows_out * g.W;
-    float* yout = y + (((size_t)n * g.H + r0) * g.W) * g.cout + c;
-    for (int p = wave; p < npix; p += 4) {
-        const int oy = p / g.W, ox = p - oy * g.W;              // uniform; row inside the strip
-        const int gy = r0 + oy;
-        int acc = 0, nvalid = 0;
+    // ---- phase 2: every wave walks whole rows.  Validity of the 3x3 taps is wave-uniform:
+    // the row class (top / middle / bottom) is fixed along a row and the column class only
+    // differs for the first and last pixel, so each class gets its own straight-line code
+    // (compile-time tap masks): nine LDS broadcast reads issued up front, no branches. ----
+    auto pixel = [&](auto rm_c, auto cm_c, int oy, int ox) {
+        constexpr int RM = decltype(rm_c)::value;      // bit dy set = row dy of the window is outside
+        constexpr int CM = decltype(cm_c)::value;      // bit dx set = column dx is outside
+        uint2 a[3][3][PAIRS];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int iy = gy + dy - 1;
-            if ((unsigned)iy >= (unsigned)g.H) continue;         // wave-uniform
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ix = ox + dx - 1;
-                if ((unsigned)ix >= (unsigned)g.W) continue;     // wave-uniform
-                const uint2* a = tile + ((size_t)(oy + dy) * g.W + ix) * PAIRS;   // same address in all lanes
+            for (int dx = 0; dx < 3; ++dx)
+                if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
+                    const uint2* src = tile + ((size_t)(oy + dy) * g.W + (ox + dx - 1)) * PAIRS;
 #pragma unroll
-                for (int j = 0; j < PAIRS; ++j) {
-                    const uint2 av = a[j];
-                    acc += __popc(av.x ^ wreg[(dy * 3 + dx) * CW + 2 * j]);
-                    acc += __popc(av.y ^ wreg[(dy * 3 + dx) * CW + 2 * j + 1]);
+                    for (int j = 0; j < PAIRS; ++j) a[dy][dx][j] = src[j];
                 }
-                ++nvalid;
-            }
-        }
+        int acc = 0;
+        int nvalid = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
+#pragma unroll
+                    for (int j = 0; j < PAIRS; ++j) {
+                        acc += __popc(a[dy][dx][j].x ^ wreg[(dy * 3 + dx) * CW + 2 * j]);
+                        acc += __popc(a[dy][dx][j].y ^ wreg[(dy * 3 + dx) * CW + 2 * j + 1]);
+                    }
+                    ++nvalid;
+                }
         float v = (float)(nvalid * g.cin - 2 * acc);
         v = __fadd_rn(v, bias);
         v = __fadd_rn(__fmul_rn(v, inv), shift);
         if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
         else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
-        yout[(size_t)p * g.cout] = v;
+        y[((((size_t)n * g.H + r0 + oy) * g.W) + ox) * g.cout + c] = v;
+    };
+    auto walk_row = [&](auto rm_c, int oy) {
+        using std::integral_constant;
+        if (g.W == 1) { pixel(rm_c, integral_constant<int, 5>{}, oy, 0); return; }
+        pixel(rm_c, integral_constant<int, 1>{}, oy, 0);
+        for (int ox = 1; ox < g.W - 1; ++ox) pixel(rm_c, integral_constant<int, 0>{}, oy, ox);
+        pixel(rm_c, integral_constant<int, 4>{}, oy, g.W - 1);
+    };
+    for (int oy = wave; oy < rows_out; oy += 4) {
+        using std::integral_constant;
+        const int gy = r0 + oy;
+        const bool top = gy == 0, bot = gy == g.H - 1;
+        if (top && bot) walk_row(integral_constant<int, 5>{}, oy);
+        else if (top) walk_row(integral_constant<int, 1>{}, oy);
+        else if (bot) walk_row(integral_constant<int, 4>{}, oy);
+        else walk_row(integral_constant<int, 0>{}, oy);
     }
 }
 
