@@ -452,21 +452,24 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
     // the row class (top / middle / bottom) is fixed along a row and the column class only
     // differs for the first and last pixel, so each class gets its own straight-line code
     // (compile-time tap masks): nine LDS broadcast reads issued up front, no branches. ----
-    auto pixel = [&](auto rm_c, auto cm_c, int oy, int ox) {
+    const bool has_bn = e.bn_inv != nullptr;
+    const float kf_cin = (float)g.cin;
+    auto pixel = [&](auto rm_c, auto cm_c, const uint2* rowbase, float* yrow, int ox) {
         constexpr int RM = decltype(rm_c)::value;      // bit dy set = row dy of the window is outside
         constexpr int CM = decltype(cm_c)::value;      // bit dx set = column dx is outside
+        constexpr int NVALID = (3 - ((RM & 1) + ((RM >> 2) & 1))) * (3 - ((CM & 1) + ((CM >> 2) & 1)));
+        // rowbase = tile row (oy+0), column 0; rows are g.W*PAIRS apart; dx is an immediate offset
+        const uint2* p0 = rowbase + (ox - 1) * PAIRS;
         uint2 a[3][3][PAIRS];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
                 if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
-                    const uint2* src = tile + ((size_t)(oy + dy) * g.W + (ox + dx - 1)) * PAIRS;
 #pragma unroll
-                    for (int j = 0; j < PAIRS; ++j) a[dy][dx][j] = src[j];
+                    for (int j = 0; j < PAIRS; ++j) a[dy][dx][j] = p0[(size_t)dy * g.W * PAIRS + dx * PAIRS + j];
                 }
         int acc = 0;
-        int nvalid = 0;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -477,21 +480,24 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
                         acc += __popc(a[dy][dx][j].x ^ wreg[(dy * 3 + dx) * CW + 2 * j]);
                         acc += __popc(a[dy][dx][j].y ^ wreg[(dy * 3 + dx) * CW + 2 * j + 1]);
                     }
-                    ++nvalid;
                 }
-        float v = (float)(nvalid * g.cin - 2 * acc);
+        // K - 2*acc: both integers < 2^24, so the float FMA below is exact
+        float v = fmaf((float)acc, -2.0f, (float)NVALID * kf_cin);
         v = __fadd_rn(v, bias);
-        v = __fadd_rn(__fmul_rn(v, inv), shift);
+        if (has_bn) v = __fadd_rn(__fmul_rn(v, inv), shift);
         if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
         else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
-        y[((((size_t)n * g.H + r0 + oy) * g.W) + ox) * g.cout + c] = v;
+        yrow[(size_t)ox * g.cout] = v;
     };
     auto walk_row = [&](auto rm_c, int oy) {
         using std::integral_constant;
-        if (g.W == 1) { pixel(rm_c, integral_constant<int, 5>{}, oy, 0); return; }
-        pixel(rm_c, integral_constant<int, 1>{}, oy, 0);
-        for (int ox = 1; ox < g.W - 1; ++ox) pixel(rm_c, integral_constant<int, 0>{}, oy, ox);
-        pixel(rm_c, integral_constant<int, 4>{}, oy, g.W - 1);
+        const uint2* rowbase = tile + (size_t)oy * g.W * PAIRS;
+        float* yrow = y + (((size_t)n * g.H + r0 + oy) * g.W) * g.cout + c;
+        if (g.W == 1) { pixel(rm_c, integral_constant<int, 5>{}, rowbase, yrow, 0); return; }
+        pixel(rm_c, integral_constant<int, 1>{}, rowbase, yrow, 0);
+#pragma unroll 2
+        for (int ox = 1; ox < g.W - 1; ++ox) pixel(rm_c, integral_constant<int, 0>{}, rowbase, yrow, ox);
+        pixel(rm_c, integral_constant<int, 4>{}, rowbase, yrow, g.W - 1);
     };
     for (int oy = wave; oy < rows_out; oy += 4) {
         using std::integral_constant;
