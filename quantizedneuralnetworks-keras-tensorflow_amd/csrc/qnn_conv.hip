@@ -18,8 +18,6 @@
 //                   packed outputs are assembled in a register and stored once.
 //   k_conv_generic  one thread per stored output element/word, runtime loops; any
 //                   shape, any stride, float32 inputs; the correctness fallback.
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "qnn_common.h"
@@ -409,20 +407,37 @@ int launch_dense(const void* x, const qnn_weights* w, const EpiArgs& e, void* y,
 // ---------------------------------------------------------------------------
 template <int CW>   // packed words per pixel (cin / 32), even
 __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e, int in_fn, int TR,
-                                                          int strips, int items, int tile_words2,
-                                                          const float* __restrict__ x,
+                                                          int strips, const float* __restrict__ x,
                                                           const uint32_t* __restrict__ wp,
                                                           float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem_x[];
-    uint2* const tiles = reinterpret_cast<uint2*>(smem_x);     // 2 x [(TR+2) rows][W][CW/2] uint2
+    uint2* tile = reinterpret_cast<uint2*>(smem_x);            // [(TR+2) rows][W][CW/2] uint2
     constexpr int PAIRS = CW / 2;
-    constexpr int U = 16;      // loads in flight per lane
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x / strips;
+    const int r0 = (blockIdx.x - n * strips) * TR;               // first output row of the strip
+    const int rows_out = min(TR, g.H - r0);
     const int cbase = blockIdx.y * 64;
-    const float thr = ((in_fn & 0xff) == QNN_FN_GRID) ? 0.0f : 0x1p-24f;  // binary_tanh(x) = +1 iff x > 2^-24
+    const float thr = (in_fn == QNN_FN_GRID) ? 0.0f : 0x1p-24f;  // binary_tanh(x) = +1 iff x > 2^-24
 
-    // ---- this lane's filter and epilogue constants (resident for the whole kernel) ----
+    // ---- phase 1: binarize rows r0-1 .. r0+rows_out into LDS ----
+    const int row_lo = max(r0 - 1, 0), row_hi = min(r0 + rows_out, g.H - 1);   // inclusive, in-image
+    const int groups = (row_hi - row_lo + 1) * g.W * PAIRS;     // 64-channel groups to convert
+    const float* xin = x + ((size_t)n * g.H + row_lo) * g.W * g.cin;
+    uint2* tdst = tile + (size_t)(row_lo - (r0 - 1)) * g.W * PAIRS;
+    constexpr int U = 16;      // loads in flight per lane: phase 1 is latency-bound otherwise
+    for (int gi = wave * U; gi < groups; gi += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (gi + u < groups) ? xin[(size_t)(gi + u) * 64 + lane] : -1.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long m = __ballot(v[u] > thr);
+            if (lane == u && gi + u < groups) tdst[gi + u] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+        }
+    }
+    // ---- this lane's filter ----
     uint32_t wreg[9 * CW];
     const uint32_t* wsrc = wp + (size_t)(cbase + lane) * (9 * CW);
 #pragma unroll
@@ -431,66 +446,41 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
     const float bias = e.bias ? e.bias[c] : 0.0f;
     const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
     const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+    __syncthreads();
+
+    // ---- phase 2: every wave walks whole rows.  Validity of the 3x3 taps is wave-uniform:
+    // the row class (top / middle / bottom) is fixed along a row and the column class only
+    // differs for the first and last pixel, so each class gets its own straight-line code
+    // (compile-time tap masks): nine LDS broadcast reads issued up front, no branches. ----
     const bool has_bn = e.bn_inv != nullptr;
     const float kf_cin = (float)g.cin;
-
-    // ---- work items: (image, strip of TR rows) ----
-    struct Item { int n, r0, rows_out, groups, toff; const float* xin; };
-    auto make_item = [&](int it) {
-        Item I;
-        I.n = it / strips;
-        I.r0 = (it - I.n * strips) * TR;
-        I.rows_out = min(TR, g.H - I.r0);
-        const int row_lo = max(I.r0 - 1, 0), row_hi = min(I.r0 + I.rows_out, g.H - 1);   // in-image rows
-        I.groups = (row_hi - row_lo + 1) * g.W * PAIRS;            // 64-channel groups to binarize
-        I.toff = (row_lo - (I.r0 - 1)) * g.W * PAIRS;              // tile row 0 is image row r0-1
-        I.xin = x + ((size_t)I.n * g.H + row_lo) * g.W * g.cin;
-        return I;
-    };
-    // phase 1 pieces: lane = channel, a 256-byte coalesced load per 64 channels; the wave's
-    // 64-bit lane mask of (x > thr) IS the packed pixel word pair
-    auto load_chunk = [&](const Item& I, int gi0, float (&v)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = (gi0 + u < I.groups) ? I.xin[(size_t)(gi0 + u) * 64 + lane] : -1.0f;
-    };
-    auto store_chunk = [&](const Item& I, int gi0, const float (&v)[U], uint2* tbuf) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned long long m = __ballot(v[u] > thr);
-            if (lane == u && gi0 + u < I.groups) tbuf[I.toff + gi0 + u] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
-        }
-    };
-
-    // phase 2: lane = output channel; tap validity is wave-uniform, so each border class
-    // gets straight-line code (compile-time masks): nine LDS broadcast reads, no branches
     auto pixel = [&](auto rm_c, auto cm_c, const uint2* rowbase, float* yrow, int ox) {
         constexpr int RM = decltype(rm_c)::value;      // bit dy set = row dy of the window is outside
         constexpr int CM = decltype(cm_c)::value;      // bit dx set = column dx is outside
         constexpr int NVALID = (3 - ((RM & 1) + ((RM >> 2) & 1))) * (3 - ((CM & 1) + ((CM >> 2) & 1)));
+        // rowbase = tile row (oy+0), column 0; rows are g.W*PAIRS apart; dx is an immediate offset
         const uint2* p0 = rowbase + (ox - 1) * PAIRS;
         uint2 a[3][3][PAIRS];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
+#pragma unroll
+                    for (int j = 0; j < PAIRS; ++j) a[dy][dx][j] = p0[(size_t)dy * g.W * PAIRS + dx * PAIRS + j];
+                }
         int acc = 0;
-        if (!(in_fn & 0x100)) {        // bit 8 of in_fn: timing experiment, skip the contraction
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
+            for (int dx = 0; dx < 3; ++dx)
+                if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
 #pragma unroll
-                        for (int j = 0; j < PAIRS; ++j) a[dy][dx][j] = p0[(size_t)dy * g.W * PAIRS + dx * PAIRS + j];
+                    for (int j = 0; j < PAIRS; ++j) {
+                        acc += __popc(a[dy][dx][j].x ^ wreg[(dy * 3 + dx) * CW + 2 * j]);
+                        acc += __popc(a[dy][dx][j].y ^ wreg[(dy * 3 + dx) * CW + 2 * j + 1]);
                     }
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
-#pragma unroll
-                        for (int j = 0; j < PAIRS; ++j) {
-                            acc += __popc(a[dy][dx][j].x ^ wreg[(dy * 3 + dx) * CW + 2 * j]);
-                            acc += __popc(a[dy][dx][j].y ^ wreg[(dy * 3 + dx) * CW + 2 * j + 1]);
-                        }
-                    }
-        }
+                }
         // K - 2*acc: both integers < 2^24, so the float FMA below is exact
         float v = fmaf((float)acc, -2.0f, (float)NVALID * kf_cin);
         v = __fadd_rn(v, bias);
@@ -499,59 +489,24 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
         else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
         yrow[(size_t)ox * g.cout] = v;
     };
-    auto walk_row = [&](auto rm_c, const Item& I, const uint2* tile, int oy) {
+    auto walk_row = [&](auto rm_c, int oy) {
         using std::integral_constant;
         const uint2* rowbase = tile + (size_t)oy * g.W * PAIRS;
-        float* yrow = y + (((size_t)I.n * g.H + I.r0 + oy) * g.W) * g.cout + c;
+        float* yrow = y + (((size_t)n * g.H + r0 + oy) * g.W) * g.cout + c;
         if (g.W == 1) { pixel(rm_c, integral_constant<int, 5>{}, rowbase, yrow, 0); return; }
         pixel(rm_c, integral_constant<int, 1>{}, rowbase, yrow, 0);
 #pragma unroll 2
         for (int ox = 1; ox < g.W - 1; ++ox) pixel(rm_c, integral_constant<int, 0>{}, rowbase, yrow, ox);
         pixel(rm_c, integral_constant<int, 4>{}, rowbase, yrow, g.W - 1);
     };
-    auto do_row = [&](const Item& I, const uint2* tile, int oy) {
+    for (int oy = wave; oy < rows_out; oy += 4) {
         using std::integral_constant;
-        const int gy = I.r0 + oy;
+        const int gy = r0 + oy;
         const bool top = gy == 0, bot = gy == g.H - 1;
-        if (top && bot) walk_row(integral_constant<int, 5>{}, I, tile, oy);
-        else if (top) walk_row(integral_constant<int, 1>{}, I, tile, oy);
-        else if (bot) walk_row(integral_constant<int, 4>{}, I, tile, oy);
-        else walk_row(integral_constant<int, 0>{}, I, tile, oy);
-    };
-
-    // ---- persistent, software-pipelined loop over items ----
-    int it = blockIdx.x;
-    if (it >= items) return;
-    Item cur = make_item(it);
-    float v[U];
-    for (int ck = wave; ck * U < cur.groups; ck += 4) {      // prologue: first item, not overlapped
-        load_chunk(cur, ck * U, v);
-        store_chunk(cur, ck * U, v, tiles);
-    }
-    __syncthreads();
-    int buf = 0;
-    while (true) {
-        const int nit = it + gridDim.x;
-        const bool has_next = nit < items;
-        Item nxt = cur;
-        if (has_next) nxt = make_item(nit);
-        const uint2* tile = tiles + (size_t)buf * tile_words2;
-        uint2* ntile = tiles + (size_t)(buf ^ 1) * tile_words2;
-        int ck = wave;                                         // this wave's next chunk of the next item
-        for (int oy = wave; oy < cur.rows_out; oy += 4) {
-            const bool ld = has_next && ck * U < nxt.groups;
-            if (ld) load_chunk(nxt, ck * U, v);               // in flight while the row is computed
-            do_row(cur, tile, oy);
-            if (ld) { store_chunk(nxt, ck * U, v, ntile); ck += 4; }
-        }
-        if (has_next)
-            for (; ck * U < nxt.groups; ck += 4) {             // chunks beyond the row count
-                load_chunk(nxt, ck * U, v);
-                store_chunk(nxt, ck * U, v, ntile);
-            }
-        if (!has_next) break;
-        __syncthreads();
-        cur = nxt; it = nit; buf ^= 1;
+        if (top && bot) walk_row(integral_constant<int, 5>{}, oy);
+        else if (top) walk_row(integral_constant<int, 1>{}, oy);
+        else if (bot) walk_row(integral_constant<int, 4>{}, oy);
+        else walk_row(integral_constant<int, 0>{}, oy);
     }
 }
 
@@ -566,21 +521,14 @@ int try_launch_xnor_f32(const ConvGeom& g, const EpiArgs& e, int in_fn, const fl
     if (cw != 2 && cw != 4 && cw != 8) return 1;
     // strip height: whole image if it fits in ~32 KB of LDS, else as many rows as fit
     int TR = g.H;
-    while ((size_t)(TR + 2) * g.W * cw * 4 > 16384 && TR > 1) TR = (TR + 1) / 2;
+    while ((size_t)(TR + 2) * g.W * cw * 4 > 32768 && TR > 1) TR = (TR + 1) / 2;
     const int strips = (g.H + TR - 1) / TR;
-    const int tile_words2 = (TR + 2) * g.W * (cw / 2);          // uint2 entries per LDS tile
-    const size_t lds = (size_t)2 * tile_words2 * 8;             // double-buffered
-    const int items = g.N * strips;
-    const int ny = g.cout / 64;
-    int blocks = 256 * 4 / ny;                                  // persistent: 4 workgroups (16 waves) per CU
-    if (blocks > items) blocks = items;
-    const dim3 grid((unsigned)blocks, (unsigned)ny), block(kBlock);
+    const size_t lds = (size_t)(TR + 2) * g.W * cw * 4;
+    const dim3 grid((unsigned)(g.N * strips), (unsigned)(g.cout / 64)), block(kBlock);
     snprintf(name, name_len, "xnor_f32_cw%d", cw);
-    static const int ablate = getenv("QNN_XNOR_ABLATE") ? atoi(getenv("QNN_XNOR_ABLATE")) : 0;
-    if (ablate) in_fn |= 0x100;
-    if (cw == 2) hipLaunchKernelGGL(k_conv_xnor_f32<2>, grid, block, lds, s, g, e, in_fn, TR, strips, items, tile_words2, x, w->d_packed, (float*)y);
-    else if (cw == 4) hipLaunchKernelGGL(k_conv_xnor_f32<4>, grid, block, lds, s, g, e, in_fn, TR, strips, items, tile_words2, x, w->d_packed, (float*)y);
-    else hipLaunchKernelGGL(k_conv_xnor_f32<8>, grid, block, lds, s, g, e, in_fn, TR, strips, items, tile_words2, x, w->d_packed, (float*)y);
+    if (cw == 2) hipLaunchKernelGGL(k_conv_xnor_f32<2>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
+    else if (cw == 4) hipLaunchKernelGGL(k_conv_xnor_f32<4>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
+    else hipLaunchKernelGGL(k_conv_xnor_f32<8>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
     return 0;
 }
 
