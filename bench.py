@@ -33,6 +33,7 @@ WORKLOADS = {
     "vgg64_full_qnn_w4a4": 2,   # BASELINE.json configs[2]: the config the metric is quoted on
     "vgg64_full_bnn": 1,
     "vgg_large_full_qnn_w8a8": 3,
+    "imagenet224_resnet10_w4a4": 4,   # BASELINE.json configs[4]; GraphModel (residual topology), 64 images / GPU
 }
 
 
@@ -88,8 +89,9 @@ def main():
     idx = WORKLOADS[args.workload]
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
-    model = engine.FusedModel(spec)
-    N = args.batch
+    fused = idx != 4
+    model = engine.FusedModel(spec) if fused else engine.GraphModel(spec)
+    N = args.batch if fused or args.batch != BATCH else 64
     # every rank owns a full batch (weak scaling: per-GPU work fixed)
     x = torch.as_tensor(nets.synthetic_images(cf, N, nets.SEED_BASE + idx + 1000 * rank)).cuda()
 
@@ -105,7 +107,7 @@ def main():
     per_kernel = []
     cur = x
     hh, ww = H, W
-    for st in model.steps:
+    for st in (model.steps if fused else []):
         nbytes, ho, wo = step_bytes(st, N, hh, ww)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
@@ -125,6 +127,17 @@ def main():
                                macs=N * (ho * wo * st["pool"] ** 2 if st["kind"] == "conv" else 1)
                                * st["w"].shape[0] * st["w"].shape[1] * st["w"].shape[2] * st["w"].shape[3]))
         cur, hh, ww = outs, ho, wo
+    if not fused:
+        # residual topology: ~200 launches per forward; report the whole forward against the
+        # float32-surface (M0) bytes of SURVEY.md 8d instead of a single kernel
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(3):
+            model(x)
+        ev1.record()
+        torch.cuda.synchronize()
+        per_kernel.append(dict(kernel="graph_forward(all launches)", ms=ev0.elapsed_time(ev1) / 3,
+                               bytes=238248232 * N, macs=6855277184 * N))
     dom = max(range(len(per_kernel)), key=lambda i: per_kernel[i]["ms"])
 
     # ---- optional hipGraph of the whole forward (launch-bound inner loop) ----
@@ -206,15 +219,15 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": d["bytes"], "avg_launch_ms": d["ms"],
                     "note": "VALU-bound packed kernel; see kernels[].TMACps and DESIGN.md"}
-        m0_bytes = {1: 442408, 2: 442408, 3: 7237672}[idx]     # SURVEY.md 8d, float32-surface traffic per image
+        m0_bytes = {1: 442408, 2: 442408, 3: 7237672, 4: 238248232}[idx]     # SURVEY.md 8d, float32-surface traffic per image
         out = {
             "metric": "images/sec @ batch 4096, CIFAR-10 VGG full-qnn 4/4; % HBM roofline",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {1: "u1", 2: "int4", 3: "int8"}[idx],
+            "scaling": "weak", "vs_baseline": None, "dtype": {1: "u1", 2: "int4", 3: "int8", 4: "int4"}[idx],
             "data": "synthetic",
             "config": {"workload": args.workload, "batch_per_gpu": N, "global_batch": N * world,
-                       "traffic_model": "M1 (packed inter-layer tensors)", "engine": "FusedModel",
+                       "traffic_model": "M1 (packed inter-layer tensors)" if fused else "M0 (float32 surfaces)", "engine": "FusedModel" if fused else "GraphModel",
                        "conv_impl": args.impl, "hipgraph": graph is not None, "parallelism": "dp%d" % world,
                        # the metric's "% HBM roofline" in BASELINE.md's sense: float32-surface (M0) bytes
                        # per image x images/s over 8 TB/s (the fused engine does not move those bytes)
