@@ -18,6 +18,8 @@
 //                   packed outputs are assembled in a register and stored once.
 //   k_conv_generic  one thread per stored output element/word, runtime loops; any
 //                   shape, any stride, float32 inputs; the correctness fallback.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "qnn_common.h"
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
 #pragma unroll
                     for (int j = 0; j < PAIRS; ++j) a[dy][dx][j] = p0[(size_t)dy * g.W * PAIRS + dx * PAIRS + j];
                 }
-        int acc = 0;
+        int acc0 = 0, acc1 = 0;      // two independent accumulate chains
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -477,10 +479,11 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
                 if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
 #pragma unroll
                     for (int j = 0; j < PAIRS; ++j) {
-                        acc += __popc(a[dy][dx][j].x ^ wreg[(dy * 3 + dx) * CW + 2 * j]);
-                        acc += __popc(a[dy][dx][j].y ^ wreg[(dy * 3 + dx) * CW + 2 * j + 1]);
+                        acc0 = qnn_dot_bin(a[dy][dx][j].x, wreg[(dy * 3 + dx) * CW + 2 * j], acc0);
+                        acc1 = qnn_dot_bin(a[dy][dx][j].y, wreg[(dy * 3 + dx) * CW + 2 * j + 1], acc1);
                     }
                 }
+        const int acc = acc0 + acc1;
         // K - 2*acc: both integers < 2^24, so the float FMA below is exact
         float v = fmaf((float)acc, -2.0f, (float)NVALID * kf_cin);
         v = __fadd_rn(v, bias);
@@ -522,6 +525,9 @@ int try_launch_xnor_f32(const ConvGeom& g, const EpiArgs& e, int in_fn, const fl
     // strip height: whole image if it fits in ~32 KB of LDS, else as many rows as fit
     int TR = g.H;
     while ((size_t)(TR + 2) * g.W * cw * 4 > 32768 && TR > 1) TR = (TR + 1) / 2;
+    static const int tr_env = getenv("QNN_XNOR_TR") ? atoi(getenv("QNN_XNOR_TR")) : 0;
+    if (tr_env > 0 && tr_env < TR) TR = tr_env;
+    else if (tr_env == 0 && TR > 8 && (TR % 8) == 0) TR = 8;    // measured: more, smaller items overlap load and compute better
     const int strips = (g.H + TR - 1) / TR;
     const size_t lds = (size_t)(TR + 2) * g.W * cw * 4;
     const dim3 grid((unsigned)(g.N * strips), (unsigned)(g.cout / 64)), block(kBlock);
