@@ -158,8 +158,12 @@ __device__ __forceinline__ float qnn_quantized_tanh(float x, float m) {
 // ---- dot products on packed words ----------------------------------------------
 // popcount(a ^ w): number of channels whose signs differ.
 __device__ __forceinline__ int qnn_dot_bin(uint32_t a, uint32_t w, int acc) {
-    // v_bcnt_u32_b32 D = popcount(S0) + S1: keep the accumulate form (the compiler would
-    // otherwise emit bcnt(x, 0) plus a tree of v_add3, ~22 % more VALU instructions)
+    return acc + __popc(a ^ w);
+}
+// Same, with the accumulate form of v_bcnt_u32_b32 (D = popcount(S0) + S1) pinned: for
+// callers that keep several independent chains themselves (the compiler otherwise emits
+// bcnt(x, 0) plus a tree of v_add3, ~22 % more VALU instructions).
+__device__ __forceinline__ int qnn_dot_bin_chain(uint32_t a, uint32_t w, int acc) {
     const uint32_t x = a ^ w;
     int r;
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));

@@ -479,8 +479,8 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
                 if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
 #pragma unroll
                     for (int j = 0; j < PAIRS; ++j) {
-                        acc0 = qnn_dot_bin(a[dy][dx][j].x, wreg[(dy * 3 + dx) * CW + 2 * j], acc0);
-                        acc1 = qnn_dot_bin(a[dy][dx][j].y, wreg[(dy * 3 + dx) * CW + 2 * j + 1], acc1);
+                        acc0 = qnn_dot_bin_chain(a[dy][dx][j].x, wreg[(dy * 3 + dx) * CW + 2 * j], acc0);
+                        acc1 = qnn_dot_bin_chain(a[dy][dx][j].y, wreg[(dy * 3 + dx) * CW + 2 * j + 1], acc1);
                     }
                 }
         const int acc = acc0 + acc1;
