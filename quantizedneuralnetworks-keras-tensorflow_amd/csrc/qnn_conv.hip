@@ -513,6 +513,180 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fused-pipeline 1-bit conv: packed bits in, packed bits out (BN + binary_tanh + optional
+// 2x2 max-pool fused).  Same structure as k_conv_xnor_f32 (lane = output channel, filter in
+// VGPRs, activations by LDS broadcast reads), but phase 1 is a plain copy of the packed rows
+// and the output of a pixel is the wave's 64-bit lane mask of (BN(v) > 2^-24): the packed
+// word pair itself.  Max-pooling: sign(max_i t_i) = OR_i sign(t_i), i.e. a scalar OR of the
+// four masks.  Lane j parks the mask of stored pixel j; they are stored 64 pixels at a time.
+// ---------------------------------------------------------------------------
+template <int CW, int POOL>
+__global__ __launch_bounds__(kBlock) void k_conv_xnor_pk(ConvGeom g, EpiArgs e, int TRP, int strips,
+                                                         const uint32_t* __restrict__ x,
+                                                         const uint32_t* __restrict__ wp,
+                                                         uint32_t* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    uint2* tile = reinterpret_cast<uint2*>(smem_x);            // [(TR+2) rows][W][CW/2] uint2
+    constexpr int PAIRS = CW / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x / strips;
+    const int pr0 = (blockIdx.x - n * strips) * TRP;             // first stored (pooled) row of the strip
+    const int prows = min(TRP, g.Hp - pr0);                     // stored rows in this strip
+    const int r0 = pr0 * POOL;                                   // first conv row
+    const int rows_out = prows * POOL;                           // conv rows computed
+    const int cbase = blockIdx.y * 64;
+
+    // ---- phase 1: copy packed rows r0-1 .. r0+rows_out (in-image ones) into LDS ----
+    const int row_lo = max(r0 - 1, 0), row_hi = min(r0 + rows_out, g.H - 1);
+    const int nent = (row_hi - row_lo + 1) * g.W * PAIRS;       // uint2 entries
+    const uint2* xin = reinterpret_cast<const uint2*>(x) + ((size_t)n * g.H + row_lo) * g.W * PAIRS;
+    uint2* tdst = tile + (size_t)(row_lo - (r0 - 1)) * g.W * PAIRS;
+    for (int i = threadIdx.x; i < nent; i += kBlock) tdst[i] = xin[i];
+
+    uint32_t wreg[9 * CW];
+    const uint32_t* wsrc = wp + (size_t)(cbase + lane) * (9 * CW);
+#pragma unroll
+    for (int k = 0; k < 9 * CW; ++k) wreg[k] = wsrc[k];
+    const int c = cbase + lane;
+    const float bias = e.bias ? e.bias[c] : 0.0f;
+    const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
+    const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+    const bool has_bn = e.bn_inv != nullptr;
+    const float kf_cin = (float)g.cin;
+    __syncthreads();
+
+    // mask of one conv pixel (tile row oy, column ox) for border class (RM, CM)
+    auto pixel_mask = [&](auto rm_c, auto cm_c, int oy, int ox) -> unsigned long long {
+        constexpr int RM = decltype(rm_c)::value;
+        constexpr int CM = decltype(cm_c)::value;
+        constexpr int NVALID = (3 - ((RM & 1) + ((RM >> 2) & 1))) * (3 - ((CM & 1) + ((CM >> 2) & 1)));
+        const uint2* p0 = tile + (size_t)oy * g.W * PAIRS + (ox - 1) * PAIRS;
+        uint2 a[3][3][PAIRS];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
+#pragma unroll
+                    for (int j = 0; j < PAIRS; ++j) a[dy][dx][j] = p0[(size_t)dy * g.W * PAIRS + dx * PAIRS + j];
+                }
+        int acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if (!((RM >> dy) & 1) && !((CM >> dx) & 1)) {
+#pragma unroll
+                    for (int j = 0; j < PAIRS; ++j) {
+                        acc0 = qnn_dot_bin_chain(a[dy][dx][j].x, wreg[(dy * 3 + dx) * CW + 2 * j], acc0);
+                        acc1 = qnn_dot_bin_chain(a[dy][dx][j].y, wreg[(dy * 3 + dx) * CW + 2 * j + 1], acc1);
+                    }
+                }
+        float v = fmaf((float)(acc0 + acc1), -2.0f, (float)NVALID * kf_cin);   // exact: integers < 2^24
+        v = __fadd_rn(v, bias);
+        if (has_bn) v = __fadd_rn(__fmul_rn(v, inv), shift);
+        return __ballot(v > 0x1p-24f);                        // binary_tanh(v) = +1 iff v > 2^-24
+    };
+    // one stored pixel: POOL x POOL conv pixels, OR of their masks.  Row classes of the (up
+    // to two) conv rows are RMA, RMB; the column class depends on the position in the row.
+    using std::integral_constant;
+    auto stored_pixel = [&](auto rma_c, auto rmb_c, auto cma_c, auto cmb_c, int oy, int ox) {
+        unsigned long long m = pixel_mask(rma_c, cma_c, oy, ox);
+        if constexpr (POOL == 2) {
+            m |= pixel_mask(rma_c, cmb_c, oy, ox + 1);
+            m |= pixel_mask(rmb_c, cma_c, oy + 1, ox);
+            m |= pixel_mask(rmb_c, cmb_c, oy + 1, ox + 1);
+        }
+        return m;
+    };
+    auto walk = [&](auto rma_c, auto rmb_c, int prow) {
+        const int oy = prow * POOL;                              // tile row of the first conv row
+        uint32_t keep_lo = 0, keep_hi = 0;                       // lane j parks the mask of stored pixel j
+        uint32_t* yrow = y + (((size_t)n * g.Hp + pr0 + prow) * g.Wp) * e.ocw + (cbase >> 5);
+        int pend0 = 0;
+        auto flush = [&](int upto) {                             // store parked masks of pixels pend0..upto-1
+            const int j = pend0 + lane;
+            if (j < upto) {
+                uint32_t* dst = yrow + (size_t)j * e.ocw;
+                dst[0] = keep_lo;
+                dst[1] = keep_hi;
+            }
+            pend0 = upto;
+        };
+        for (int pxs = 0; pxs < g.Wp; ++pxs) {
+            const int ox = pxs * POOL;
+            unsigned long long m;
+            const bool first = ox == 0, last_a = ox == g.W - 1, last_b = (ox + 1) == g.W - 1;
+            if constexpr (POOL == 2) {
+                // conv columns ox (class A) and ox+1 (class B)
+                if (first && last_b) m = stored_pixel(rma_c, rmb_c, integral_constant<int, 1>{}, integral_constant<int, 4>{}, oy, ox);
+                else if (first) m = stored_pixel(rma_c, rmb_c, integral_constant<int, 1>{}, integral_constant<int, 0>{}, oy, ox);
+                else if (last_b) m = stored_pixel(rma_c, rmb_c, integral_constant<int, 0>{}, integral_constant<int, 4>{}, oy, ox);
+                else m = stored_pixel(rma_c, rmb_c, integral_constant<int, 0>{}, integral_constant<int, 0>{}, oy, ox);
+            } else {
+                if (first && last_a) m = stored_pixel(rma_c, rmb_c, integral_constant<int, 5>{}, integral_constant<int, 5>{}, oy, ox);
+                else if (first) m = stored_pixel(rma_c, rmb_c, integral_constant<int, 1>{}, integral_constant<int, 1>{}, oy, ox);
+                else if (last_a) m = stored_pixel(rma_c, rmb_c, integral_constant<int, 4>{}, integral_constant<int, 4>{}, oy, ox);
+                else m = stored_pixel(rma_c, rmb_c, integral_constant<int, 0>{}, integral_constant<int, 0>{}, oy, ox);
+            }
+            const int slot = pxs - pend0;                        // 0..63, wave-uniform
+            if (lane == slot) { keep_lo = (uint32_t)m; keep_hi = (uint32_t)(m >> 32); }
+            if (slot == 63) flush(pxs + 1);
+        }
+        flush(g.Wp);
+    };
+    for (int prow = wave; prow < prows; prow += 4) {
+        const int gy = r0 + prow * POOL;                         // image row of conv row A
+        const bool top_a = gy == 0, bot_a = gy == g.H - 1;
+        if constexpr (POOL == 2) {
+            const bool bot_b = (gy + 1) == g.H - 1;              // row B is never the top row
+            if (top_a && bot_b) walk(integral_constant<int, 1>{}, integral_constant<int, 4>{}, prow);
+            else if (top_a) walk(integral_constant<int, 1>{}, integral_constant<int, 0>{}, prow);
+            else if (bot_b) walk(integral_constant<int, 0>{}, integral_constant<int, 4>{}, prow);
+            else walk(integral_constant<int, 0>{}, integral_constant<int, 0>{}, prow);
+        } else {
+            if (top_a && bot_a) walk(integral_constant<int, 5>{}, integral_constant<int, 5>{}, prow);
+            else if (top_a) walk(integral_constant<int, 1>{}, integral_constant<int, 1>{}, prow);
+            else if (bot_a) walk(integral_constant<int, 4>{}, integral_constant<int, 4>{}, prow);
+            else walk(integral_constant<int, 0>{}, integral_constant<int, 0>{}, prow);
+        }
+    }
+}
+
+// returns 0 if launched
+int try_launch_xnor_pk(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w,
+                       void* y, hipStream_t s, char* name, size_t name_len) {
+    if (w->store != QNN_STORE_BIN || !w->d_packed) return 1;
+    if (g.kh != 3 || g.kw != 3 || g.stride != 1 || !w->same_pad) return 1;
+    if (g.cin % 64 != 0 || g.cout % 64 != 0) return 1;
+    if (e.out_store != QNN_STORE_BIN || e.fn != QNN_FN_BINARY_TANH) return 1;
+    if (g.W < 2 || (g.pool == 2 && (g.W < 2 || g.H < 2))) return 1;
+    const int cw = g.cin / 32;
+    if (cw != 2 && cw != 4 && cw != 8) return 1;
+    // strip = TRP stored rows; LDS tile = (TRP*pool + 2) conv rows
+    int TRP = g.Hp;
+    while ((size_t)(TRP * g.pool + 2) * g.W * cw * 4 > 32768 && TRP > 1) TRP = (TRP + 1) / 2;
+    const int strips = (g.Hp + TRP - 1) / TRP;
+    const size_t lds = (size_t)(TRP * g.pool + 2) * g.W * cw * 4;
+    const dim3 grid((unsigned)(g.N * strips), (unsigned)(g.cout / 64)), block(kBlock);
+    snprintf(name, name_len, "xnor_pk_cw%d", cw);
+#define XPK_CASE(CW_)                                                                              \
+    if (cw == CW_) {                                                                               \
+        if (g.pool == 2)                                                                           \
+            hipLaunchKernelGGL((k_conv_xnor_pk<CW_, 2>), grid, block, lds, s, g, e, TRP, strips,   \
+                               (const uint32_t*)x, w->d_packed, (uint32_t*)y);                     \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_conv_xnor_pk<CW_, 1>), grid, block, lds, s, g, e, TRP, strips,   \
+                               (const uint32_t*)x, w->d_packed, (uint32_t*)y);                     \
+        return 0;                                                                                  \
+    }
+    XPK_CASE(2) XPK_CASE(4) XPK_CASE(8)
+#undef XPK_CASE
+    return 1;
+}
+
 // returns 0 if launched
 int try_launch_xnor_f32(const ConvGeom& g, const EpiArgs& e, int in_fn, const float* x,
                         const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len) {
@@ -702,6 +876,8 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     }
     if (!launched && pref != 1 && !dense)
         launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
+    if (!launched && x_store == QNN_STORE_BIN && !dense)
+        launched = try_launch_xnor_pk(g, e, x, w, y, s, name, sizeof(name)) == 0;
     if (!launched) launched = try_launch_ps(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
     if (launched) {
         qnn_set_kernel_name(name);

@@ -343,6 +343,27 @@ def test_layer_surface_xnor_fused(shape, with_bn):
     assert torch.equal(y, y3)
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64), (2, 8, 8, 64, 64), (2, 5, 7, 128, 64), (1, 28, 28, 64, 128),
+                                   (1, 32, 32, 256, 128), (2, 40, 24, 64, 192), (1, 2, 2, 64, 64), (2, 7, 7, 64, 64)])
+@pytest.mark.parametrize("pool", [1, 2])
+def test_packed_xnor_kernel(shape, pool):
+    """packed bits in -> XNOR conv -> BN -> binary_tanh (-> 2x2 max-pool) -> packed bits out."""
+    N, H, W, C, Cout = shape
+    if pool == 2 and (H < 2 or W < 2):
+        pytest.skip("no pool window")
+    rng = np.random.default_rng(zlib.crc32(repr((shape, pool)).encode()))
+    x = O.binary_tanh(rng.standard_normal((N, H, W, C)).astype(F32))
+    op = {"op": "conv", "kind": "binary", "kernel": rng.uniform(-1, 1, (3, 3, C, Cout)).astype(F32),
+          "bias": (rng.standard_normal(Cout) * 0.05).astype(F32), "strides": (1, 1), "padding": "same"}
+    bn = _rand_bn(rng, Cout, 9.0 * C)
+    _abi.set_conv_impl(_abi.IMPL_AUTO)
+    got, kern = _run_group(x, BIN_ACT, op, bn, BIN_ACT, pool, _abi.STORE_BIN)
+    assert kern.startswith("xnor_pk_cw"), kern
+    np.testing.assert_array_equal(got, _oracle_group(x, op, bn, BIN_ACT, pool))
+    got2, _ = _run_group(x, BIN_ACT, op, None, BIN_ACT, pool, _abi.STORE_BIN)     # no BN
+    np.testing.assert_array_equal(got2, _oracle_group(x, op, None, BIN_ACT, pool))
+
+
 @pytest.mark.parametrize("kind,nb,in_act", [("binary", None, BIN_ACT), ("quantized", 4, Q(4)),
                                             ("quantized", 8, Q(8)), ("quantized", 4, None)])
 def test_dense_layer(kind, nb, in_act):
