@@ -498,7 +498,6 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
         float* yrow = y + (((size_t)n * g.H + r0 + oy) * g.W) * g.cout + c;
         if (g.W == 1) { pixel(rm_c, integral_constant<int, 5>{}, rowbase, yrow, 0); return; }
         pixel(rm_c, integral_constant<int, 1>{}, rowbase, yrow, 0);
-#pragma unroll 2
         for (int ox = 1; ox < g.W - 1; ++ox) pixel(rm_c, integral_constant<int, 0>{}, rowbase, yrow, ox);
         pixel(rm_c, integral_constant<int, 4>{}, rowbase, yrow, g.W - 1);
     };
