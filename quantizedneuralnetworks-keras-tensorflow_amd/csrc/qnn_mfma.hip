@@ -565,6 +565,170 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 3 : 2)) void k_conv_first_mfma(Conv
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Same layer, operands through LDS: every wave stages the float32 patch of its 32-pixel
+// tile (plus a zero halo) into a wave-private LDS tile with coalesced bounds-checked
+// buffer loads, and the lanes fetch their MFMA A operands with ds_read_b32 at
+// loop-invariant addresses -- the per-tap border logic and 64-bit address arithmetic of
+// the gather version disappear from the VALU stream (which is additive with the f32 MFMA).
+// Filters of channels with a negative BN scale are negated on load (exactly negating the
+// FMA chain), so max-pooling needs only v_max; the sign is restored before the epilogue.
+// Tiling: POOL==2: 8 pool windows in a row = conv rows 2*py..2*py+1 x 16 columns (needs
+// Wp % 8 == 0); POOL==1: 32 pixels in a row (needs W % 32 == 0).  No barriers: the LDS
+// tile is private to the wave.
+template <int CIN, int NT, int OUT, int POOL>
+__global__ __launch_bounds__(256, 3) void k_conv_first_lds(ConvGeom g, EpiArgs e,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ wq,
+                                                           void* __restrict__ y, long total_q,
+                                                           int tiles, int tiles_per_row,
+                                                           FastDiv fd_tpr, uint32_t x_bytes) {
+    constexpr int K = 9 * CIN;
+    constexpr int KS = (K + 1) / 2;
+    constexpr int TROWS = (POOL == 2) ? 4 : 3;        // conv rows + halo
+    constexpr int TCOLS = (POOL == 2) ? 18 : 34;      // conv cols + halo
+    constexpr int TE = TROWS * TCOLS * CIN;           // floats per tile
+    constexpr int NJ = (TE + 63) / 64;                // staging loads per lane
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wv = threadIdx.x >> 6;
+    float* lds = reinterpret_cast<float*>(smem_f) + wv * (2 * TE);   // two buffers per wave
+    const int wave_id = blockIdx.x * 4 + wv;
+    const int nwaves = gridDim.x * 4;
+    const int cbase = blockIdx.y * (NT * 32);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
+
+    // ---- per-lane constants ----
+    LaneEpi ke[NT];
+    float wb[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        lane_epi_init<OUT>(ke[nt], e, cbase + nt * 32 + li, li);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 2 * s + lh;
+            float w = k < K ? wq[(long)(cbase + nt * 32 + li) * K + k] : 0.0f;
+            wb[nt][s] = (POOL == 2 && ke[nt].neg) ? -w : w;
+        }
+    }
+    // staging: element ej = lane + 64*j of the [TROWS][TCOLS][CIN] tile
+    int st_goff[NJ], st_r[NJ], st_c[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int ej = lane + 64 * j;
+        const int r = ej / (TCOLS * CIN), rem = ej - r * (TCOLS * CIN);
+        const int col = rem / CIN, ch = rem - col * CIN;
+        st_r[j] = (ej < TE) ? r : -100000;
+        st_c[j] = col;
+        st_goff[j] = ((r * g.W + col) * CIN + ch) * 4;
+    }
+    // operand k = 2s+lh of this lane's pixel: LDS word index relative to the tile
+    int lrow, lcol;
+    if constexpr (POOL == 2) { lrow = (li & 3) >> 1; lcol = 2 * (li >> 2) + (li & 1); }
+    else { lrow = 0; lcol = li; }
+    int op_idx[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + lh;
+        const int kk = k < K ? k : 0;
+        const int tap = kk / CIN, ch = kk - tap * CIN;
+        op_idx[s] = ((lrow + tap / 3) * TCOLS + (lcol + tap % 3)) * CIN + ch;
+    }
+    const bool kpad = (K & 1) && lh == 1;          // lane half 1 of the last k-step is padding
+
+    auto tile_origin = [&](int t, int& n, int& oy0, int& ox0) {
+        const uint32_t trow = qnn_div((uint32_t)t, fd_tpr);           // = n*rows + row
+        const int tb = t - (int)trow * tiles_per_row;
+        const int rows_per_img = (POOL == 2) ? g.Hp : g.H;
+        const FastDiv& fdh = g.fd_hp;                                  // Hp == H when POOL == 1
+        n = (int)qnn_div(trow, fdh);
+        const int rr = (int)trow - n * rows_per_img;
+        oy0 = rr * POOL;
+        ox0 = tb * ((POOL == 2) ? 16 : 32);
+    };
+    float stg[NJ];
+    auto stage_load = [&](int t) {
+        int n, oy0, ox0;
+        tile_origin(t, n, oy0, ox0);
+        const int base4 = (((n * g.H + (oy0 - 1)) * g.W + (ox0 - 1)) * CIN) * 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool ok = (unsigned)(oy0 - 1 + st_r[j]) < (unsigned)g.H &&
+                            (unsigned)(ox0 - 1 + st_c[j]) < (unsigned)g.W;
+            const int voff = ok ? base4 + st_goff[j] : (int)0x80000000;      // out of range -> 0.0f (the halo)
+            stg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, 0, 0));
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lane + 64 * j < TE) lds[buf * TE + lane + 64 * j] = stg[j];
+    };
+
+    int t = wave_id;
+    if (t >= tiles) return;
+    stage_load(t);
+    stage_write(0);
+    stage_load(min(t + nwaves, tiles - 1));        // unconditional (clamped): keeps the waits counted
+    int buf = 0;
+    for (; t < tiles; t += nwaves) {
+        // ---- A operands of this tile from LDS ----
+        float av[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) av[s] = lds[buf * TE + op_idx[s]];
+        if (kpad) av[KS - 1] = 0.0f;
+        // ---- hand the next tile to the other buffer, start the loads of the one after ----
+        stage_write(buf ^ 1);
+        stage_load(min(t + 2 * nwaves, tiles - 1));
+        int n, oy0, ox0;
+        tile_origin(t, n, oy0, ox0);
+        // stored-pixel index of this tile's first window / pixel
+        const long q_base = (POOL == 2) ? ((long)n * g.Hp + (oy0 >> 1)) * g.Wp + (ox0 >> 1)
+                                        : ((long)n * g.H + oy0) * g.W + ox0;
+#pragma unroll
+        for (int nc = 0; nc < NT; nc += 2) {
+            v16f acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wb[nc + u][s], acc[u], 0, 0, 0);
+            if constexpr (POOL == 2) {
+                float tv[8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float m = fmaxf(fmaxf(acc[u][4 * g4], acc[u][4 * g4 + 1]),
+                                              fmaxf(acc[u][4 * g4 + 2], acc[u][4 * g4 + 3]));
+                        tv[u * 4 + g4] = bn_apply(ke[nc + u].neg ? -m : m, ke[nc + u]);
+                    }
+                // tile row R = 8*g4 + 4*lh + s is window R/4 = 2*g4 + lh
+                store_values<OUT, 8>(tv, ke[0], e, li,
+                    [&](int j) { return q_base + 2 * (j & 3) + lh; },
+                    [&](int j) { return cbase + (nc + (j >> 2)) * 32 + li; }, total_q, g.cout, y);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = bn_apply(acc[u][r], ke[nc + u]);
+                    store_values<OUT, 16>(tv, ke[nc + u], e, li,
+                        [&](int j) { return q_base + (j & 3) + 8 * (j >> 2) + 4 * lh; },
+                        [&](int) { return cbase + (nc + u) * 32 + li; }, total_q, g.cout, y);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
 template <int CIN, int NT>
 int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float* wq, void* y,
                  hipStream_t s) {
@@ -578,8 +742,38 @@ int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float
     const dim3 grid((unsigned)blocks, (unsigned)ny), block(256);
     const float* xf = (const float*)x;
     const double xb = (double)g.N * g.H * g.W * CIN * 4.0;
-    if (xb >= 4.0e9) return 1;                  // 32-bit buffer offsets
+    if (xb >= 2.0e9) return 1;                  // 31-bit buffer offsets
     const uint32_t x_bytes = (uint32_t)xb;
+    static const int no_lds = getenv("QNN_FIRST_GATHER") ? atoi(getenv("QNN_FIRST_GATHER")) : 0;
+    const bool lds_ok = !no_lds && g.stride == 1 && g.pt == 1 && g.pl == 1 &&
+                        ((g.pool == 2 && (g.Wp % 8) == 0 && (g.H % 2) == 0 && (g.W % 2) == 0) ||
+                         (g.pool == 1 && (g.W % 32) == 0));
+    if (lds_ok) {
+        const int tpr = g.pool == 2 ? g.Wp / 8 : g.W / 32;
+        const int rows = g.pool == 2 ? g.Hp : g.H;
+        const long ntiles = (long)g.N * rows * tpr;
+        if (ntiles < 2.0e9) {
+            long lblocks = (ntiles + 3) / 4;
+            const long lmax = 256 * 3 / ny;
+            if (lblocks > lmax) lblocks = lmax;
+            const dim3 lgrid((unsigned)lblocks, (unsigned)ny);
+            const FastDiv fd_tpr = qnn_fastdiv((uint32_t)tpr);
+            const size_t lds_bytes = (size_t)4 * 2 * ((g.pool == 2 ? 4 * 18 : 3 * 34) * CIN) * 4;
+#define FIRST_LDS_CASE(OUT)                                                                      \
+            if (e.out_store == OUT) {                                                            \
+                if (g.pool == 2)                                                                 \
+                    hipLaunchKernelGGL((k_conv_first_lds<CIN, NT, OUT, 2>), lgrid, block, lds_bytes, s, g, e, xf, wq, y, total_q, (int)ntiles, tpr, fd_tpr, x_bytes); \
+                else                                                                             \
+                    hipLaunchKernelGGL((k_conv_first_lds<CIN, NT, OUT, 1>), lgrid, block, lds_bytes, s, g, e, xf, wq, y, total_q, (int)ntiles, tpr, fd_tpr, x_bytes); \
+                return 0;                                                                        \
+            }
+            FIRST_LDS_CASE(QNN_STORE_F32)
+            FIRST_LDS_CASE(QNN_STORE_BIN)
+            FIRST_LDS_CASE(QNN_STORE_I4)
+            FIRST_LDS_CASE(QNN_STORE_I8)
+#undef FIRST_LDS_CASE
+        }
+    }
 #define FIRST_CASE(OUT)                                                                      \
     if (e.out_store == OUT) {                                                                \
         if (g.pool == 2)                                                                     \
