@@ -178,11 +178,9 @@ __device__ __forceinline__ void store_values(const float (&t)[NV], const LaneEpi
         for (int g = 0; g < NV / 8; ++g) {
             uint32_t P = pack_own<4, 8>(&t[8 * g], e);
             P = transpose_nib8(P, k) ^ 0x88888888u;
-            long q = total_q;
-            int c = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if ((li & 7) == j) { q = qof(8 * g + j); c = cof(8 * g + j); }
+            const int jl = 8 * g + (li & 7);       // after the transpose lane (li&7) holds word jl
+            const long q = qof(jl);
+            const int c = cof(jl);
             if (q < total_q) ((uint32_t*)y)[q * e.ocw + (c >> 3)] = P;
         }
     } else {
@@ -191,11 +189,9 @@ __device__ __forceinline__ void store_values(const float (&t)[NV], const LaneEpi
         for (int g = 0; g < NV / 4; ++g) {
             uint32_t P = pack_own<8, 4>(&t[4 * g], e);
             P = transpose_byte4(P, k) ^ 0x80808080u;
-            long q = total_q;
-            int c = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((li & 3) == j) { q = qof(4 * g + j); c = cof(4 * g + j); }
+            const int jl = 4 * g + (li & 3);
+            const long q = qof(jl);
+            const int c = cof(jl);
             if (q < total_q) ((uint32_t*)y)[q * e.ocw + (c >> 2)] = P;
         }
     }
@@ -745,7 +741,7 @@ int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float
     if (xb >= 2.0e9) return 1;                  // 31-bit buffer offsets
     const uint32_t x_bytes = (uint32_t)xb;
     static const int no_lds = getenv("QNN_FIRST_GATHER") ? atoi(getenv("QNN_FIRST_GATHER")) : 0;
-    const bool lds_ok = !no_lds && g.stride == 1 && g.pt == 1 && g.pl == 1 &&
+    const bool lds_ok = !no_lds && NT == 2 && g.stride == 1 && g.pt == 1 && g.pl == 1 &&
                         ((g.pool == 2 && (g.Wp % 8) == 0 && (g.H % 2) == 0 && (g.W % 2) == 0) ||
                          (g.pool == 1 && (g.W % 32) == 0));
     if (lds_ok) {
