@@ -76,12 +76,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("QNN_DIST_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
 
     pkg = importlib.import_module(PKG)
     nets, engine, shard, abi = pkg.nets, pkg.engine, pkg.shard, pkg._abi
@@ -97,7 +98,11 @@ def main():
 
     def step():
         y = model(x)
-        return shard.gather_logits(y) if world > 1 else y
+        if world == 1:
+            return y
+        if backend == "gloo":                      # rehearsal path: gloo gathers host tensors
+            return shard.gather_logits(y.cpu())
+        return shard.gather_logits(y)
 
     # ---- per-kernel HIP-event timing (same stream the kernels are launched on) ----
     for _ in range(3):
@@ -179,7 +184,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
