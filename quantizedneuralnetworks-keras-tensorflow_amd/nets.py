@@ -264,4 +264,80 @@ def synthetic_images(cf, n, seed=0):
     return (x.astype(F32) / F32(255)).astype(F32)
 
 
+def spec_from_keras_npz(path, wbits=None, abits=None):
+    """Rebuild a net spec from a Keras 2.1.3 checkpoint converted by tools/import_keras_hdf5.py
+    (counterpart of test_resnet.py:44-66 build + load_weights).  The topology comes from the
+    embedded model_config, so the shipped results/RESNET3/*.hdf5 files -- saved from an older
+    ResNet variant with use_bias=True and without the 0.5 scaling -- load as they were trained.
+    `nb` is not serialised by the reference (get_config omits it, quantized_layers.py:91-96):
+    pass wbits / abits (the two-character code of the file name: '44' -> 4, 4)."""
+    import json
+    d = np.load(path)
+    cfg = json.loads(bytes(d["model_config_json"]).decode())
+    layers = cfg["config"]["layers"]
+    spec = []
+    first = True
+    for l in layers:
+        cls, c, name = l["class_name"], l["config"], l["name"]
+        inbound = [ib[0] for ib in l["inbound_nodes"][0]] if l["inbound_nodes"] else []
+        if cls == "InputLayer":
+            spec_alias = name
+            continue
+        src = inbound[0] if inbound else None
+        if src == spec_alias:
+            src = "input"
+        op = None
+        if cls in ("QuantizedConv2D", "BinaryConv2D", "Conv2D"):
+            kind = {"QuantizedConv2D": "quantized", "BinaryConv2D": "binary", "Conv2D": "float"}[cls]
+            op = {"op": "conv", "kind": kind, "kernel": d[name + "/kernel"],
+                  "bias": d[name + "/bias"] if c.get("use_bias", True) else None,
+                  "strides": tuple(c["strides"]), "padding": c["padding"],
+                  "klm": np.float32(c.get("kernel_lr_multiplier") or 1.0)}
+            if kind == "quantized":
+                op["nb"] = int(wbits)
+        elif cls in ("QuantizedDense", "BinaryDense", "Dense"):
+            kind = {"QuantizedDense": "quantized", "BinaryDense": "binary", "Dense": "float"}[cls]
+            op = {"op": "dense", "kind": kind, "kernel": d[name + "/kernel"],
+                  "bias": d[name + "/bias"] if c.get("use_bias", True) else None}
+            if kind == "quantized":
+                op["nb"] = int(abits)          # model_factory.py:31: Fc gets nb=cf.abits
+        elif cls == "BatchNormalization":
+            op = {"op": "bn", "eps": float(c["epsilon"]), "gamma": d[name + "/gamma"],
+                  "beta": d[name + "/beta"], "mean": d[name + "/moving_mean"],
+                  "var": d[name + "/moving_variance"]}
+        elif cls == "Activation":
+            fn = c["activation"]
+            if fn == "quantized_relu":         # local name of quantize_op, model_factory.py:19-20
+                op = {"op": "act", "fn": "quantized_tanh", "nb": int(abits)}
+            elif fn in ("binary_tanh", "ternary_tanh"):
+                op = {"op": "act", "fn": fn}
+            else:
+                raise ValueError("unsupported activation %r" % fn)
+        elif cls == "LeakyReLU":
+            op = {"op": "act", "fn": "leaky_relu", "alpha": float(c.get("alpha", 0.3))}
+        elif cls == "Add":
+            op = {"op": "add", "a": "input" if inbound[0] == spec_alias else inbound[0], "b": inbound[1]}
+            src = None
+        elif cls == "Lambda":
+            op = {"op": "scale", "value": 0.5}
+        elif cls == "AveragePooling2D":
+            op = {"op": "avgpool", "size": int(c["pool_size"][0])}
+        elif cls == "MaxPooling2D":
+            op = {"op": "maxpool", "size": int(c["pool_size"][0])}
+        elif cls == "ZeroPadding2D":
+            op = {"op": "zeropad", "pad": int(c["padding"][0][0])}
+        elif cls == "Flatten":
+            op = {"op": "flatten"}
+        else:
+            raise ValueError("unsupported layer class %r" % cls)
+        if src is not None:
+            op["src"] = src
+        op["dst"] = name
+        spec.append(op)
+        first = False
+        if cls in ("QuantizedDense", "BinaryDense", "Dense") and c.get("activation") == "softmax":
+            spec.append({"op": "softmax", "src": name, "dst": name + "_softmax"})
+    return spec
+
+
 SEED_BASE = 20240607

@@ -115,3 +115,17 @@ def test_baseline_specs_shapes():
     x = nets.synthetic_images(cf, 3, 7)
     assert x.shape == (3, 32, 32, 3) and x.dtype == np.float32 and x.max() <= 1.0
     assert np.array_equal(np.rint(x * 255), x * np.float32(255))
+
+
+def test_spec_from_reference_checkpoint_runs_in_oracle():
+    """tools/import_keras_hdf5.py + nets.spec_from_keras_npz on the reference's trained
+    weights_44.hdf5: 21 quantized convs (use_bias=True), 19 BN, 9 adds, softmax dense."""
+    from oracle import qnn_oracle as O
+    path = os.path.join(ROOT, "tests", "golden", "resnet3_full_44.npz")
+    spec = nets.spec_from_keras_npz(path, 4, 4)
+    kinds = [op["op"] for op in spec]
+    assert kinds.count("conv") == 21 and kinds.count("bn") == 19 and kinds.count("add") == 9
+    assert kinds[-1] == "softmax" and "scale" not in kinds
+    assert all(op["bias"] is not None for op in spec if op["op"] == "conv")
+    y = O.run_spec(spec, nets.synthetic_images(nets.Config(dim=32), 2, 3))
+    assert y.shape == (2, 10) and np.allclose(y.sum(-1), 1.0, atol=1e-5)

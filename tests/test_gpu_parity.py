@@ -472,6 +472,26 @@ def test_resnet_small(nt, wb, ab):
         np.testing.assert_allclose(lm, want, atol=1e-6)
 
 
+@pytest.mark.parametrize("code,wb,ab", [("44", 4, 4), ("bb", None, None)])
+def test_trained_reference_checkpoint_end_to_end(code, wb, ab):
+    """The reference's own trained ResNet-20 (results/RESNET3/weights_*.hdf5, imported with
+    tools/import_keras_hdf5.py; older topology: conv biases, no 0.5 scaling) through the
+    engine and the oracle."""
+    spec = nets.spec_from_keras_npz(os.path.join(GOLD, "resnet3_full_%s.npz" % code), wb, ab)
+    assert sum(op["op"] == "conv" for op in spec) == 21
+    x = nets.synthetic_images(nets.Config(dim=32), 5, 11)
+    env = O.run_spec(spec, x, float_conv="device", return_all=True)
+    want = list(env.values())[-1]
+    got = host(engine.GraphModel(spec)(dev(x)))
+    np.testing.assert_allclose(got, want, atol=1e-6)          # softmax: exp differs in the last ulp
+    assert np.array_equal(got.argmax(-1), want.argmax(-1))
+    np.testing.assert_allclose(host(engine.LayerModel(spec)(dev(x))), want, atol=1e-6)
+    # the pre-softmax logits are bit-exact
+    logits_name = [op["dst"] for op in spec if op["op"] == "dense"][0]
+    g = engine.GraphModel(spec[:-1])
+    np.testing.assert_array_equal(host(g(dev(x))), env[logits_name])
+
+
 def test_mnist_resnet_zero_padding():
     cf = nets.Config(network_type="full-bnn", architecture="RESNET", dataset="MNIST", dim=28,
                      channels=1, nres=1)
