@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define QNN_ABI_VERSION 1
+#define QNN_ABI_VERSION 2
 
 /* status codes */
 #define QNN_OK            0
@@ -76,6 +76,9 @@ typedef struct qnn_weights qnn_weights_t;   /* opaque prepacked layer weights */
  *   v = v + bias[c]                           K.bias_add   (if the layer has bias)
  *   v = v*bn_inv[c] + bn_shift[c]             inference BatchNormalization, two
  *                                             roundings (vgg.py:16, resnet.py:61)
+ *   v = (res[pixel][c] + v) * post_scale      residual merge of models/resnet.py:127-128:
+ *                                             keras.layers.add([x, y]) then Lambda(x*0.5);
+ *                                             only if res != NULL (pool must be 1)
  *   v = fn(v)                                 binary_tanh / quantized_tanh(act_bits)
  *   v = max over a pool x pool window         MaxPooling2D(2,2) (vgg.py:23,30,37)
  *   store as out_store (F32 value, or packed code)
@@ -89,6 +92,11 @@ typedef struct qnn_epilogue {
     int32_t act_bits;        /* nb of quantized_tanh (ignored otherwise)         */
     int32_t pool;            /* 1 = none, 2 = 2x2 max pool stride 2 'valid'      */
     int32_t out_store;       /* QNN_STORE_F32 | _BIN | _I4 | _I8                 */
+    /* residual input (shortcut branch), same pixels x cout as the output, or NULL */
+    const void* res;         /* DEVICE: float32 NHWC, or packed codes              */
+    int32_t res_store;       /* QNN_STORE_F32 | _BIN | _I4 | _I8                   */
+    int32_t res_bits;        /* packed: value = code / 2^(res_bits-1) (BIN: +-1)    */
+    float post_scale;        /* multiplier after the add (0.5 in resnet.py:128; 1 = none) */
 } qnn_epilogue_t;
 
 /* ---- library ------------------------------------------------------------ */

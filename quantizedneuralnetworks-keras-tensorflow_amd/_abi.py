@@ -29,7 +29,9 @@ EXPORTS = [
 class Epilogue(ctypes.Structure):
     _fields_ = [("bn_inv", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
                 ("fn", ctypes.c_int32), ("act_bits", ctypes.c_int32),
-                ("pool", ctypes.c_int32), ("out_store", ctypes.c_int32)]
+                ("pool", ctypes.c_int32), ("out_store", ctypes.c_int32),
+                ("res", ctypes.c_void_p), ("res_store", ctypes.c_int32), ("res_bits", ctypes.c_int32),
+                ("post_scale", ctypes.c_float)]
 
 
 class QnnError(RuntimeError):
@@ -200,8 +202,14 @@ def out_hw(size, k, stride, same_pad):
     return (size - k) // stride + 1
 
 
+def make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res=None, res_store=STORE_F32,
+                  res_bits=0, post_scale=1.0):
+    return Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store,
+                    ptr(res).value, res_store, res_bits, float(post_scale))
+
+
 def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
-           pool=1, out_store=STORE_F32):
+           pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0):
     """Run qnn_conv2d_forward; x is a float32 NHWC tensor or an int32 packed tensor.
     Returns (y, Hp, Wp): y float32 (N,Hp,Wp,cout) or int32 (N*Hp*Wp, words)."""
     kh, kw, cin, cout = w.shape
@@ -211,7 +219,7 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
         y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
     else:
         y = torch.empty((N * Ho * Wo, words(out_store, cout)), dtype=torch.int32, device=x.device)
-    epi = Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store)
+    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale)
     check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
                                     ptr(y), stream_ptr()), "qnn_conv2d_forward")
     return y, Ho, Wo
@@ -231,7 +239,7 @@ def conv2d_f32in(w, x, in_fn, in_bits, bn_inv=None, bn_shift=None, fn=FN_NONE, a
         y = torch.empty((N * Ho * Wo, words(out_store, cout)), dtype=torch.int32, device=x.device)
     need = load().qnn_conv2d_workspace_bytes(w.handle, N, H, W)
     ws = torch.empty((max(need, 4) + 3) // 4, dtype=torch.int32, device=x.device)
-    epi = Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store)
+    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store)
     check(load().qnn_conv2d_forward_f32in(w.handle, ptr(x), in_fn, in_bits, N, H, W, ctypes.byref(epi),
                                           ptr(y), ptr(ws), ws.numel() * 4, stream_ptr()),
           "qnn_conv2d_forward_f32in")
@@ -245,7 +253,7 @@ def dense(w, x, x_store, x_bits, N, bn_inv=None, bn_shift=None, fn=FN_NONE, act_
         y = torch.empty((N, cout), dtype=torch.float32, device=x.device)
     else:
         y = torch.empty((N, words(out_store, cout)), dtype=torch.int32, device=x.device)
-    epi = Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, 1, out_store)
+    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, 1, out_store)
     check(load().qnn_dense_forward(w.handle, ptr(x), x_store, x_bits, N, ctypes.byref(epi), ptr(y),
                                    stream_ptr()), "qnn_dense_forward")
     return y

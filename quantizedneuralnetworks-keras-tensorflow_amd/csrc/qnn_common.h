@@ -98,6 +98,11 @@ struct EpiArgs {
     int fn;
     int out_store;
     int ocw;                   // words per stored output pixel (packed) or cout (f32)
+    const void* res;           // residual tensor (same pixels x cout) or nullptr
+    int res_store;
+    int res_cw;                // words (packed) or floats (f32) per residual pixel
+    float res_scale;           // 2^-(res_bits-1)
+    float post_scale;
 };
 
 #ifdef __HIPCC__
@@ -190,6 +195,26 @@ __device__ __forceinline__ float qnn_epi_value(float v, int c, const EpiArgs& e)
     if (e.bias) v = __fadd_rn(v, e.bias[c]);
     if (e.bn_inv) v = __fadd_rn(__fmul_rn(v, e.bn_inv[c]), e.bn_shift[c]);
     return v;
+}
+// residual merge of models/resnet.py:127-128: (x + y) * post_scale, float32, two roundings
+__device__ __forceinline__ float qnn_epi_residual(float v, long q, int c, const EpiArgs& e) {
+    if (!e.res) return v;
+    float r;
+    if (e.res_store == QNN_STORE_F32) {
+        r = ((const float*)e.res)[q * e.res_cw + c];
+    } else if (e.res_store == QNN_STORE_BIN) {
+        const uint32_t w = ((const uint32_t*)e.res)[q * e.res_cw + (c >> 5)];
+        r = ((w >> (c & 31)) & 1u) ? 1.0f : -1.0f;
+    } else if (e.res_store == QNN_STORE_I4) {
+        const uint32_t w = ((const uint32_t*)e.res)[q * e.res_cw + (c >> 3)];
+        const int code = (int)(w << (28 - 4 * (c & 7))) >> 28;
+        r = __fmul_rn((float)code, e.res_scale);
+    } else {
+        const uint32_t w = ((const uint32_t*)e.res)[q * e.res_cw + (c >> 2)];
+        const int code = (int)(w << (24 - 8 * (c & 3))) >> 24;
+        r = __fmul_rn((float)code, e.res_scale);
+    }
+    return __fmul_rn(__fadd_rn(r, v), e.post_scale);
 }
 // value -> stored code (BIN: 0/1; I4/I8: signed code) or float bits
 __device__ __forceinline__ int qnn_epi_code(float v, const EpiArgs& e) {

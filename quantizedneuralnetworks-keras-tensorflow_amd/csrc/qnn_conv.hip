@@ -183,6 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_generic(ConvGeom g, EpiArgs e, 
                 const int oy = py * g.pool + s / g.pool, ox = px * g.pool + s % g.pool;
                 float v = conv_point(g, x_store, x, wp, wq, e.scale, n, oy, ox, c);
                 v = qnn_epi_value(v, c, e);
+                v = qnn_epi_residual(v, (long)q, c, e);
                 if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
                 else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
                 best = (s == 0) ? v : fmaxf(best, v);
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_generic(ConvGeom g, EpiArgs e, 
                     const int oy = py * g.pool + s / g.pool, ox = px * g.pool + s % g.pool;
                     float v = conv_point(g, x_store, x, wp, wq, e.scale, n, oy, ox, c);
                     v = qnn_epi_value(v, c, e);
+                    v = qnn_epi_residual(v, (long)q, c, e);
                     const int code = qnn_epi_code(v, e);
                     best = (s == 0) ? code : max(best, code);
                 }
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_ps(ConvGeom g, EpiArgs e,
                 v = __fmul_rn((float)acc, e.scale);
             }
             v = qnn_epi_value(v, c, e);
+            v = qnn_epi_residual(v, (long)q, c, e);
             if constexpr (OUT == QNN_STORE_F32) {
                 if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
                 else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
@@ -795,6 +798,28 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
                     "epilogue: act_bits=%d", epi->act_bits);
         e->act_m = (float)(1u << (epi->act_bits - 1));
     }
+    e->res = epi->res;
+    e->res_store = epi->res_store;
+    e->res_cw = 0;
+    e->res_scale = 1.0f;
+    e->post_scale = epi->res ? epi->post_scale : 1.0f;
+    if (epi->res) {
+        QNN_REQUIRE(epi->pool == 1, QNN_EINVAL, "epilogue: a residual input cannot be combined with pooling");
+        switch (epi->res_store) {
+            case QNN_STORE_F32: e->res_cw = w->cout; break;
+            case QNN_STORE_BIN: e->res_cw = qnn_words(QNN_STORE_BIN, w->cout); break;
+            case QNN_STORE_I4:
+            case QNN_STORE_I8:
+                QNN_REQUIRE(epi->res_bits >= 1 && epi->res_bits <= epi->res_store, QNN_EINVAL,
+                            "epilogue: res_bits=%d does not fit %d-bit storage", epi->res_bits, epi->res_store);
+                e->res_cw = qnn_words(epi->res_store, w->cout);
+                e->res_scale = ldexpf(1.0f, -(epi->res_bits - 1));
+                break;
+            default:
+                qnn_set_error("epilogue: res_store=%d", epi->res_store);
+                return QNN_EINVAL;
+        }
+    }
     switch (epi->out_store) {
         case QNN_STORE_F32:
             e->ocw = w->cout;
@@ -864,7 +889,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     // required: the remainder row/column is simply never produced)
     const int pref = qnn_conv_impl_pref();
     bool launched = false;
-    if (dense && x_store != QNN_STORE_F32 && e.out_store == QNN_STORE_F32 && (w->kwords % 4) == 0) {
+    if (dense && !e.res && x_store != QNN_STORE_F32 && e.out_store == QNN_STORE_F32 && (w->kwords % 4) == 0) {
         int rc2 = x_store == QNN_STORE_BIN  ? launch_dense<QNN_STORE_BIN>(x, w, e, y, N, s)
                   : x_store == QNN_STORE_I4 ? launch_dense<QNN_STORE_I4>(x, w, e, y, N, s)
                                             : launch_dense<QNN_STORE_I8>(x, w, e, y, N, s);
@@ -873,9 +898,9 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
             snprintf(name, sizeof(name), "dense_%s", x_store == QNN_STORE_BIN ? "bin" : x_store == QNN_STORE_I4 ? "i4" : "i8");
         }
     }
-    if (!launched && pref != 1 && !dense)
+    if (!launched && pref != 1 && !dense && !e.res)
         launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
-    if (!launched && x_store == QNN_STORE_BIN && !dense)
+    if (!launched && x_store == QNN_STORE_BIN && !dense && !e.res)
         launched = try_launch_xnor_pk(g, e, x, w, y, s, name, sizeof(name)) == 0;
     if (!launched) launched = try_launch_ps(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
     if (launched) {
@@ -1041,7 +1066,7 @@ extern "C" int qnn_conv2d_forward_f32in(const qnn_weights_t* w, const float* x, 
                 QNN_EINVAL, "qnn_conv2d_forward_f32in: in_fn=%d", in_fn);
     const int x_bits = w->store == QNN_STORE_BIN ? 1 : in_bits;
     if (w->store == QNN_STORE_BIN && epi->out_store == QNN_STORE_F32 && epi->pool == 1 && N > 0 &&
-        qnn_conv_impl_pref() != 2) {
+        !epi->res && qnn_conv_impl_pref() != 2) {
         ConvGeom g;
         g.N = N; g.H = H; g.W = W;
         g.cin = w->cin; g.cout = w->cout; g.kh = w->kh; g.kw = w->kw; g.stride = w->stride;

@@ -340,6 +340,258 @@ class GraphModel:
 
 
 # ---------------------------------------------------------------------------
+class _Packed:
+    """A packed activation tensor: int32 words (pixels, cw) + what the codes mean."""
+
+    def __init__(self, t, store, bits, shape):
+        self.t, self.store, self.bits, self.shape = t, store, bits, tuple(shape)   # shape: NHWC or (N, K)
+
+    def to_f32(self):
+        n = 1
+        for d in self.shape[:-1]:
+            n *= d
+        return _abi.unpack(self.t, n, self.shape[-1], self.store, self.bits).reshape(self.shape)
+
+
+class ResidualFusedModel:
+    """Packed, fused execution of arbitrary (residual) specs -- SURVEY.md 8f.1.
+
+    Every `conv -> BN -> act` chain and every residual merge
+    `conv -> BN -> add(shortcut) -> [x0.5] -> act` (models/resnet.py:108-129) is ONE kernel
+    launch whose epilogue reads the shortcut (packed codes of the previous activation, or the
+    float32 output of the 1x1 projection) and writes the next activation packed.  Evaluation is
+    demand-driven from the output so the shortcut operand is always computed before the conv
+    that merges it.  Anything that is not on the low-bit path (avg-pool, softmax, ...) runs as
+    float32 torch ops on unpacked tensors.
+    """
+
+    def __init__(self, spec, device="cuda"):
+        self.device = torch.device(device)
+        self.spec = spec
+        self.names = [op.get("dst", "t%d" % i) for i, op in enumerate(spec)]
+        self.prod = {n: i for i, n in enumerate(self.names)}
+        self.srcs = []
+        for i, op in enumerate(spec):
+            if op["op"] == "add":
+                self.srcs.append([op["a"], op["b"]])
+            elif "src" in op:
+                self.srcs.append([op["src"]])
+            else:
+                self.srcs.append([self.names[i - 1] if i > 0 else "input"])
+        self.cons = {}
+        for i, ss in enumerate(self.srcs):
+            for s_ in ss:
+                self.cons.setdefault(s_, []).append(i)
+        self._w = {}
+        self._bn = {}
+        for i, op in enumerate(spec):
+            if op["op"] == "bn":
+                inv, shift = bn_constants(op)
+                self._bn[i] = (torch.as_tensor(inv).to(self.device), torch.as_tensor(shift).to(self.device))
+        self.kernel_log = None
+
+    # ---- helpers -----------------------------------------------------------------
+    def _weights(self, i, store):
+        key = (i, store)
+        if key not in self._w:
+            op = self.spec[i]
+            st = tuple(op.get("strides", (1, 1)))
+            self._w[key] = _prepack(op, store, self.device, stride=st[0],
+                                    same_pad=op.get("padding", "same") == "same")
+        return self._w[key]
+
+    def _single(self, name, kind):
+        """Index of the op producing `name` if it is of `kind` and `name` has one consumer."""
+        i = self.prod.get(name)
+        if i is None or self.spec[i]["op"] != kind or len(self.cons.get(name, [])) != 1:
+            return None
+        return i
+
+    def _act_out_store(self, name, bits):
+        """Packed store the consumers of activation `name` want, or None if one needs float32."""
+        joins = []
+        for ci in self.cons.get(name, []):
+            op = self.spec[ci]
+            if op["op"] in ("conv", "dense") and _wstore(op) is not None:
+                joins.append(_join_store(bits, _wstore(op)))
+            elif op["op"] in ("add", "flatten"):
+                continue
+            else:
+                return None
+        if not joins:
+            return _abi.STORE_BIN if bits == 1 else _abi.store_for_bits(bits)
+        if all(j == _abi.STORE_BIN for j in joins):
+            return _abi.STORE_BIN
+        return max([j for j in joins if j != _abi.STORE_BIN] + [_abi.STORE_I4])
+
+    # ---- evaluation --------------------------------------------------------------
+    def forward(self, x):
+        x = _abi.require_cuda(x, "ResidualFusedModel.forward")
+        memo = {"input": x}
+
+        def f32(name):
+            v = ev(name)
+            return v.to_f32() if isinstance(v, _Packed) else v
+
+        def conv_call(ci, bn_i, res, post_scale, fn, bits, out_store):
+            """Launch conv `ci` with everything fused behind it."""
+            op = self.spec[ci]
+            src = ev(self.srcs[ci][0])
+            inv, shift = self._bn[bn_i] if bn_i is not None else (None, None)
+            rkw = {}
+            if res is not None:
+                if isinstance(res, _Packed):
+                    rkw = dict(res=res.t, res_store=res.store, res_bits=res.bits, post_scale=post_scale)
+                else:
+                    rkw = dict(res=res.contiguous(), res_store=_abi.STORE_F32, res_bits=0, post_scale=post_scale)
+            ab = bits if fn == _abi.FN_QUANTIZED_TANH else 0
+            if isinstance(src, _Packed) and _wstore(op) is None:
+                src = src.to_f32()               # stock float conv: float32 route
+            if isinstance(src, _Packed):
+                N, H, W, C = src.shape
+                w = self._weights(ci, src.store)
+                y, Ho, Wo = _abi.conv2d(w, src.t, src.store, src.bits, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
+            else:
+                N, H, W, C = src.shape
+                w = self._weights(ci, _abi.STORE_F32)
+                y, Ho, Wo = _abi.conv2d(w, src.contiguous(), _abi.STORE_F32, 0, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
+            if self.kernel_log is not None:
+                self.kernel_log.append(_abi.last_kernel())
+            cout = op["kernel"].shape[3]
+            if out_store == _abi.STORE_F32:
+                return y
+            return _Packed(y, out_store, bits, (N, Ho, Wo, cout))
+
+        def conv_bn_of(name):
+            """(conv index, bn index or None) if `name` is conv or conv->bn with single consumers."""
+            b = self._single(name, "bn")
+            if b is not None:
+                c = self._single(self.srcs[b][0], "conv")
+                if c is not None:
+                    return c, b
+                return None
+            c = self._single(name, "conv")
+            if c is not None:
+                return c, None
+            return None
+
+        def ev(name):
+            if name in memo:
+                return memo[name]
+            i = self.prod[name]
+            op = self.spec[i]
+            kind = op["op"]
+            out = None
+            if kind == "act":
+                ac = _act_code(op)
+                pre_name = self.srcs[i][0]
+                if ac is not None:
+                    fn, bits = ac
+                    store = self._act_out_store(name, bits)
+                    out_store = store if store is not None else _abi.STORE_F32
+                    # pattern 1: conv -> bn -> act
+                    cb = conv_bn_of(pre_name)
+                    if cb is not None and _ok_lowbit(self.spec[cb[0]]):
+                        out = conv_call(cb[0], cb[1], None, 1.0, fn, bits, out_store)
+                    else:
+                        # pattern 2: conv -> bn -> add(shortcut) -> [scale] -> act
+                        sc_i = self._single(pre_name, "scale")
+                        add_name = self.srcs[sc_i][0] if sc_i is not None else pre_name
+                        post = float(self.spec[sc_i]["value"]) if sc_i is not None else 1.0
+                        ad_i = self._single(add_name, "add")
+                        if ad_i is not None:
+                            a_n, b_n = self.srcs[ad_i]
+                            for main, short in ((b_n, a_n), (a_n, b_n)):
+                                cb = conv_bn_of(main)
+                                if cb is not None and _ok_lowbit(self.spec[cb[0]]):
+                                    res = ev(short)
+                                    out = conv_call(cb[0], cb[1], res, post, fn, bits, out_store)
+                                    break
+                    if out is None:      # no fusable producer: clip (+pack) the float32 tensor
+                        pre = f32(pre_name)
+                        if store is not None:
+                            C = pre.shape[-1]
+                            nb_in = bits if fn == _abi.FN_QUANTIZED_TANH else 1
+                            out = _Packed(_abi.pack(pre, C, fn, nb_in, store), store, bits, pre.shape)
+                        else:
+                            out = (binary_ops.binary_tanh(pre) if fn == _abi.FN_BINARY_TANH
+                                   else quantized_ops.quantized_tanh(pre, bits))
+                else:
+                    pre = f32(pre_name)
+                    fnn = op["fn"]
+                    if fnn == "quantized_tanh":
+                        out = quantized_ops.quantized_tanh(pre, op["nb"])
+                    elif fnn == "ternary_tanh":
+                        out = ternary_ops.ternary_tanh(pre)
+                    elif fnn == "leaky_relu":
+                        out = torch.where(pre >= 0, pre, pre * F32(op.get("alpha", 0.3)))
+                    else:
+                        raise ValueError(fnn)
+            elif kind == "bn":
+                cb = conv_bn_of(name)
+                if cb is not None:
+                    out = conv_call(cb[0], cb[1], None, 1.0, _abi.FN_NONE, 0, _abi.STORE_F32)
+                else:
+                    inv, shift = self._bn[i]
+                    out = f32(self.srcs[i][0]) * inv + shift
+            elif kind == "conv":
+                out = conv_call(i, None, None, 1.0, _abi.FN_NONE, 0, _abi.STORE_F32)
+            elif kind == "dense":
+                src = ev(self.srcs[i][0])
+                if isinstance(src, _Packed) and _wstore(op) is not None:
+                    w = self._weights(i, src.store)
+                    out = _abi.dense(w, src.t, src.store, src.bits, src.shape[0])
+                else:
+                    xin = src.to_f32() if isinstance(src, _Packed) else src
+                    out = _abi.dense(self._weights(i, _abi.STORE_F32), xin.contiguous(), _abi.STORE_F32, 0, xin.shape[0])
+            elif kind == "flatten":
+                src = ev(self.srcs[i][0])
+                if isinstance(src, _Packed) and src.shape[-1] % _abi.per_word(src.store) == 0:
+                    N = src.shape[0]
+                    k = 1
+                    for d in src.shape[1:]:
+                        k *= d
+                    out = _Packed(src.t, src.store, src.bits, (N, k))
+                else:
+                    t = src.to_f32() if isinstance(src, _Packed) else src
+                    out = t.reshape(t.shape[0], -1)
+            elif kind == "add":
+                out = f32(self.srcs[i][0]) + f32(self.srcs[i][1])
+            elif kind == "scale":
+                out = f32(self.srcs[i][0]) * F32(op["value"])
+            elif kind == "maxpool":
+                t = f32(self.srcs[i][0]); s_ = op.get("size", 2)
+                N, H, W, C = t.shape
+                out = t[:, :H // s_ * s_, :W // s_ * s_, :].reshape(N, H // s_, s_, W // s_, s_, C).amax(dim=(2, 4))
+            elif kind == "avgpool":
+                t = f32(self.srcs[i][0]); s_ = op.get("size", 8)
+                N, H, W, C = t.shape
+                win = t[:, :H // s_ * s_, :W // s_ * s_, :].reshape(N, H // s_, s_, W // s_, s_, C)
+                out = win.double().sum(dim=(2, 4)).float() / F32(s_ * s_)
+            elif kind == "zeropad":
+                p_ = op["pad"]
+                out = torch.nn.functional.pad(f32(self.srcs[i][0]), (0, 0, p_, p_, p_, p_))
+            elif kind == "softmax":
+                out = torch.softmax(f32(self.srcs[i][0]).double(), dim=-1).float()
+            else:
+                raise ValueError(kind)
+            memo[name] = out
+            return out
+
+        res = ev(self.names[-1])
+        return res.to_f32() if isinstance(res, _Packed) else res
+
+    __call__ = forward
+    predict = forward
+
+
+def _ok_lowbit(op):
+    """Convs the fused epilogue path takes: low-bit weights (packed input) or the float-input
+    first layer; stock float convs stay on the float32 route."""
+    return op["op"] == "conv" and op["kind"] in ("binary", "quantized") and op.get("nb", 1) <= 8
+
+
+# ---------------------------------------------------------------------------
 class LayerModel:
     """The spec instantiated as Keras-compatible layer objects, called one by one
     (every low-bit layer: float32 NHWC in -> float32 NHWC out)."""

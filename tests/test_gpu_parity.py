@@ -42,7 +42,7 @@ def edge_values():
 # ---------------------------------------------------------------------------
 def test_native_library_is_what_runs():
     assert os.path.exists(_abi.lib_path())
-    assert _abi.load().qnn_version() == 1
+    assert _abi.load().qnn_version() == 2
 
 
 def test_binary_tanh_matches_oracle():
@@ -490,6 +490,46 @@ def test_trained_reference_checkpoint_end_to_end(code, wb, ab):
     logits_name = [op["dst"] for op in spec if op["op"] == "dense"][0]
     g = engine.GraphModel(spec[:-1])
     np.testing.assert_array_equal(host(g(dev(x))), env[logits_name])
+
+
+@pytest.mark.parametrize("nt,wb,ab", [("full-qnn", 4, 4), ("full-bnn", 1, 1), ("qbnn", 1, 4),
+                                      ("full-qnn", 2, 8), ("full-qnn", 8, 4), ("qnn", 4, 4)])
+@pytest.mark.parametrize("nres", [1, 2])
+def test_residual_fused_model(nt, wb, ab, nres):
+    """conv->BN->add(shortcut)->x0.5->act fused into one launch, activations packed end to end."""
+    cf = nets.Config(network_type=nt, wbits=wb, abits=ab, architecture="RESNET", nres=nres, dim=32)
+    spec = nets.build_spec(cf, 77)
+    x = nets.synthetic_images(cf, 3, 77)
+    want = O.run_spec(spec, x, float_conv="device")
+    m = engine.ResidualFusedModel(spec)
+    m.kernel_log = []
+    got = host(m(dev(x)))
+    np.testing.assert_allclose(got, want, atol=2e-5 if nt == "qnn" else 1e-6)
+    if nt != "qnn":
+        # logits before the softmax are bit-exact, and nothing fell back to the generic kernel
+        logits_name = [op["dst"] for op in spec if op["op"] == "dense"][0]
+        env = O.run_spec(spec, x, float_conv="device", return_all=True)
+        np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec[:-1])(dev(x))), env[logits_name])
+        assert "generic" not in m.kernel_log, m.kernel_log
+        assert len(m.kernel_log) == sum(op["op"] == "conv" for op in spec)
+
+
+@pytest.mark.parametrize("code,wb,ab", [("44", 4, 4), ("bb", None, None)])
+def test_residual_fused_model_on_trained_checkpoint(code, wb, ab):
+    spec = nets.spec_from_keras_npz(os.path.join(GOLD, "resnet3_full_%s.npz" % code), wb, ab)
+    x = nets.synthetic_images(nets.Config(dim=32), 4, 12)
+    env = O.run_spec(spec, x, float_conv="device", return_all=True)
+    logits_name = [op["dst"] for op in spec if op["op"] == "dense"][0]
+    np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec[:-1])(dev(x))), env[logits_name])
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_residual_fused_model_runs_vgg_too(idx):
+    cf = nets.baseline_config(idx)
+    spec = nets.build_spec(cf, nets.SEED_BASE + idx)
+    x = nets.synthetic_images(cf, 4, 3)
+    np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec)(dev(x))),
+                                  O.run_spec(spec, x, float_conv="device"))
 
 
 def test_mnist_resnet_zero_padding():
