@@ -301,6 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_ps(ConvGeom g, EpiArgs e,
 #pragma unroll(OUT == QNN_STORE_F32 ? 4 : 2)
         for (int b = 0; b < PWO; ++b) {
             const int c = c0 + b;
+            if (OUT != QNN_STORE_F32 && c >= g.cout) break;      // partial last word (wave-uniform)
             const uint32_t* w = wts + (long)c * KWORDS;
             float v;
             if constexpr (XS == QNN_STORE_F32) {
@@ -746,8 +747,7 @@ int launch_ps_out(const ConvGeom& g, const EpiArgs& e, const void* x, const uint
 int try_launch_ps(const ConvGeom& g, const EpiArgs& e, int x_store, const void* x,
                   const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len) {
     if (g.kh != g.kw || (g.kh != 3 && g.kh != 1)) return 1;
-    const int pwo = e.out_store == QNN_STORE_F32 ? 4 : qnn_per_word(e.out_store);
-    if (g.cout % pwo != 0) return 1;
+    if (e.out_store == QNN_STORE_F32 && g.cout % 4 != 0) return 1;   // float4 stores
     if (g.pool != 1 && g.pool != 2) return 1;
     const uint32_t* wts = x_store == QNN_STORE_F32 ? (const uint32_t*)w->d_wq : w->d_packed;
     const int32_t* corr = (x_store == QNN_STORE_BIN && w->same_pad && g.kh == 3) ? w->d_corr : nullptr;
@@ -776,6 +776,9 @@ int try_launch_ps(const ConvGeom& g, const EpiArgs& e, int x_store, const void* 
     PS_CASE(QNN_STORE_I8, 4, 3)
     PS_CASE(QNN_STORE_I8, 8, 3)
     PS_CASE(QNN_STORE_I8, 16, 3)
+    PS_CASE(QNN_STORE_I8, 4, 1)
+    PS_CASE(QNN_STORE_I8, 8, 1)
+    PS_CASE(QNN_STORE_I8, 16, 1)
 #undef PS_CASE
     return 1;
 }
