@@ -33,7 +33,7 @@ WORKLOADS = {
     "vgg64_full_qnn_w4a4": 2,   # BASELINE.json configs[2]: the config the metric is quoted on
     "vgg64_full_bnn": 1,
     "vgg_large_full_qnn_w8a8": 3,
-    "imagenet224_resnet10_w4a4": 4,   # BASELINE.json configs[4]; GraphModel (residual topology), 64 images / GPU
+    "imagenet224_resnet10_w4a4": 4,   # BASELINE.json configs[4]; ResidualFusedModel, 64 images / GPU
 }
 
 
@@ -91,7 +91,7 @@ def main():
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     fused = idx != 4
-    model = engine.FusedModel(spec) if fused else engine.GraphModel(spec)
+    model = engine.FusedModel(spec) if fused else engine.ResidualFusedModel(spec)
     N = args.batch if fused or args.batch != BATCH else 64
     # every rank owns a full batch (weak scaling: per-GPU work fixed)
     x = torch.as_tensor(nets.synthetic_images(cf, N, nets.SEED_BASE + idx + 1000 * rank)).cuda()
@@ -141,8 +141,8 @@ def main():
             model(x)
         ev1.record()
         torch.cuda.synchronize()
-        per_kernel.append(dict(kernel="graph_forward(all launches)", ms=ev0.elapsed_time(ev1) / 3,
-                               bytes=238248232 * N, macs=6855277184 * N))
+        per_kernel.append(dict(kernel="residual_forward(all launches)", ms=ev0.elapsed_time(ev1) / 3,
+                               bytes=30307912 * N, macs=6855277184 * N))   # M1 bytes/img, SURVEY.md 8d
     dom = max(range(len(per_kernel)), key=lambda i: per_kernel[i]["ms"])
 
     # ---- optional hipGraph of the whole forward (launch-bound inner loop) ----
@@ -232,7 +232,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": {1: "u1", 2: "int4", 3: "int8", 4: "int4"}[idx],
             "data": "synthetic",
             "config": {"workload": args.workload, "batch_per_gpu": N, "global_batch": N * world,
-                       "traffic_model": "M1 (packed inter-layer tensors)" if fused else "M0 (float32 surfaces)", "engine": "FusedModel" if fused else "GraphModel",
+                       "traffic_model": "M1 (packed inter-layer tensors)", "engine": "FusedModel" if fused else "ResidualFusedModel",
                        "conv_impl": args.impl, "hipgraph": graph is not None, "parallelism": "dp%d" % world,
                        # the metric's "% HBM roofline" in BASELINE.md's sense: float32-surface (M0) bytes
                        # per image x images/s over 8 TB/s (the fused engine does not move those bytes)
