@@ -198,7 +198,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                prefix = ("k_conv_first_mfma" if d["kernel"].startswith("mfma_f32_first") else
+                prefix = ("k_conv_first" if d["kernel"].startswith("mfma_f32_first") else
                           "k_conv_mfma" if d["kernel"].startswith("mfma_i") else
                           "k_conv_ps" if d["kernel"].startswith("ps_") else
                           "k_dense_packed" if d["kernel"].startswith("dense_") else "k_conv_generic")
