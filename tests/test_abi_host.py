@@ -129,3 +129,26 @@ def test_spec_from_reference_checkpoint_runs_in_oracle():
     assert all(op["bias"] is not None for op in spec if op["op"] == "conv")
     y = O.run_spec(spec, nets.synthetic_images(nets.Config(dim=32), 2, 3))
     assert y.shape == (2, 10) and np.allclose(y.sum(-1), 1.0, atol=1e-5)
+
+
+def test_fused_chain_grouping_and_residual_planning():
+    """Host-side planning (no GPU): FusedModel groups conv/bn/act/pool chains; the residual
+    planner finds producers, consumers and the storage every activation is wanted in."""
+    from qnn_amd import engine
+    cf = nets.baseline_config(2)
+    groups = engine.FusedModel._group(nets.build_spec(cf, 1))
+    assert [g["kind"] for g in groups] == ["conv", "conv", "conv", "dense"]
+    assert [g["pool"] for g in groups] == [2, 2, 2, 1]
+    assert all(g["bn"] is not None for g in groups) and groups[-1]["act"] is None
+    rcf = nets.Config(network_type="full-qnn", wbits=4, abits=4, architecture="RESNET", nres=1, dim=32)
+    rspec = nets.build_spec(rcf, 2)
+    assert engine.FusedModel._group(rspec) is None          # residual topology is not a chain
+    m = engine.ResidualFusedModel(rspec, device="cpu")
+    acts = [n for n, i in m.prod.items() if rspec[i]["op"] == "act"]
+    stores = {m._act_out_store(n, 4) for n in acts}
+    assert stores == {_abi.STORE_I4, None}                  # the last activation feeds the avg-pool (float32)
+    adds = [i for i, op in enumerate(rspec) if op["op"] == "add"]
+    assert len(adds) == 3 and all(len(m.srcs[i]) == 2 for i in adds)
+    bcf = nets.Config(network_type="full-bnn", architecture="RESNET", nres=1, dim=32)
+    mb = engine.ResidualFusedModel(nets.build_spec(bcf, 2), device="cpu")
+    assert _abi.STORE_BIN in {mb._act_out_store(n, 1) for n, i in mb.prod.items() if mb.spec[i]["op"] == "act"}
