@@ -138,7 +138,8 @@ int qnn_unpack_f32(const void* x, float* y, size_t pixels, int channels,
  *   bias        : DEVICE pointer [cout] or NULL (use_bias=False)
  *   stride      : 1 or 2 (square); same_pad: 1 = 'same', 0 = 'valid'
  *   store       : packed kind to prepare for the integer path (QNN_STORE_BIN only
- *                 for QNN_W_BINARY; I4 needs wbits<=4; I8 needs wbits<=8), or
+ *                 for QNN_W_BINARY; I4 needs wbits<=4; I8 needs wbits<=8; ternary
+ *                 weights {-1,0,1} use I4 or I8), or
  *                 QNN_STORE_F32 for "float32 inputs only" (first layer).
  */
 int qnn_prepack_weights(int wkind, int wbits, float H, const float* kernel,

@@ -406,6 +406,24 @@ def quantized_dense_call(x, kernel, bias=None, nb=16):
     return bias_add(out, bias) if bias is not None else out
 
 
+def _ternary_kernel(kernel, H, mode):
+    """ternarize(W, H) (ternary_ops.py:33-41).  'faithful' replays W + (Wt - W) in float32,
+    which leaves some weights one ulp off {-H, 0, H}; 'exact' takes it as Wt."""
+    return _ternarize(kernel, H) if mode == "exact" else ternarize(kernel, H)
+
+
+def ternary_conv2d_call(x, kernel, bias=None, H=1.0, strides=(1, 1), padding="same", mode="exact"):
+    """TernaryConv2D.call, ternary_layers.py:156-174 (no lr-multiplier trick in this layer)."""
+    out = _conv(x, _ternary_kernel(kernel, H, mode), strides, padding)
+    return bias_add(out, bias) if bias is not None else out
+
+
+def ternary_dense_call(x, kernel, bias=None, H=1.0, mode="exact"):
+    """TernaryDense.call, ternary_layers.py:77-84."""
+    out = dot(x, _ternary_kernel(kernel, H, mode))
+    return bias_add(out, bias) if bias is not None else out
+
+
 def float_conv2d_call(x, kernel, bias=None, strides=(1, 1), padding="same"):
     """Stock keras Conv2D (network_type 'float', model_factory.py:24-26)."""
     out = _conv(x, kernel, strides, padding)
@@ -488,6 +506,8 @@ def _run_spec(spec, x, mode, promotion, return_all):
             elif lk == "quantized":
                 y = quantized_conv2d_call(src, op["kernel"], op.get("bias"), op["nb"],
                                           op.get("klm"), st, pad, mode, promotion)
+            elif lk == "ternary":
+                y = ternary_conv2d_call(src, op["kernel"], op.get("bias"), op.get("H", 1.0), st, pad, mode)
             elif lk == "float":
                 y = float_conv2d_call(src, op["kernel"], op.get("bias"), st, pad)
             else:
@@ -498,6 +518,8 @@ def _run_spec(spec, x, mode, promotion, return_all):
                 y = binary_dense_call(src, op["kernel"], op.get("bias"), op.get("H", 1.0))
             elif lk == "quantized":
                 y = quantized_dense_call(src, op["kernel"], op.get("bias"), op["nb"])
+            elif lk == "ternary":
+                y = ternary_dense_call(src, op["kernel"], op.get("bias"), op.get("H", 1.0), mode)
             elif lk == "float":
                 y = dot(src, op["kernel"])
                 if op.get("bias") is not None:

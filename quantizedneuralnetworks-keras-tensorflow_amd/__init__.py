@@ -19,9 +19,11 @@ from .layers.ternary_ops import ternary_tanh, ternarize  # noqa: F401
 from .layers.binary_layers import BinaryConv2D, BinaryDense, BinaryConvolution2D  # noqa: F401
 from .layers.quantized_layers import (QuantizedConv2D, QuantizedDense,  # noqa: F401
                                       QuantizedConvolution2D)
+from .layers.ternary_layers import TernaryConv2D, TernaryDense, TernaryConvolution2D  # noqa: F401
 
 __all__ = [
     "binary_tanh", "binarize", "binary_sigmoid", "quantize", "quantized_tanh",
     "ternary_tanh", "ternarize", "BinaryConv2D", "BinaryDense", "BinaryConvolution2D",
     "QuantizedConv2D", "QuantizedDense", "QuantizedConvolution2D",
+    "TernaryConv2D", "TernaryDense", "TernaryConvolution2D",
 ]

@@ -47,6 +47,7 @@ struct qnn_weights {
     int32_t* d_corr;      // BIN + same_pad: [64][cout] zero-padding corrections
     uint8_t* d_mfma;      // int8 image [cout][kh*kw][cin] for the MFMA kernel (may alias d_packed)
     void* d_mfma_own;     // owned allocation behind d_mfma (I4 store), or nullptr
+    void* d_aux;          // ternary: the 0.7*mean|W| cutoff (1 float), else nullptr
 };
 
 struct ConvGeom;

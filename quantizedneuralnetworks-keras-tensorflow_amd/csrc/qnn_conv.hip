@@ -31,23 +31,47 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------
 // weights: quantize + pack on device (once per set_weights)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float quantize_weight(float w, int wkind, float H, float m) {
+__device__ __forceinline__ float quantize_weight(float w, int wkind, float H, float m, float cutoff) {
     if (wkind == QNN_W_BINARY) return __fmul_rn(H, qnn_binary_tanh(__fdiv_rn(w, H)));
     if (wkind == QNN_W_QUANT) return qnn_quantized_tanh(w, m);
+    if (wkind == QNN_W_TERNARY) {
+        // ternary_ops.py:21-27: W/H > cutoff -> 1, W/H <= -cutoff -> -1, else 0; times H.
+        // ("exact" mode: the straight-through W + (Wt - W) of ternary_ops.py:41 is taken as Wt.)
+        const float u = __fdiv_rn(w, H);
+        const float t = u > cutoff ? 1.0f : (u <= -cutoff ? -1.0f : 0.0f);
+        return __fmul_rn(t, H);
+    }
     return w;
+}
+
+// ternary_ops.py:15-30: cutoff = 0.7 * mean(|W / H|) over the WHOLE kernel.  One block,
+// fixed reduction order (deterministic), double accumulation.
+__global__ __launch_bounds__(1024) void k_tern_cutoff(const float* __restrict__ kernel, int n, float H,
+                                                      float* __restrict__ cutoff) {
+    __shared__ double part[1024];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) s += (double)fabsf(__fdiv_rn(kernel[i], H));
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cutoff[0] = __fmul_rn(0.7f, (float)(part[0] / (double)n));
 }
 
 // d_wq[c][t][ci] = quantizer(kernel_hwio[t][ci][c])
 __global__ __launch_bounds__(kBlock) void k_prepack_float(const float* __restrict__ kernel,
                                                           float* __restrict__ wq, int taps,
                                                           int cin, int cout, int wkind, float H,
-                                                          float m) {
+                                                          float m, const float* __restrict__ cutoff_p) {
     const int total = cout * taps * cin;
+    const float cutoff = cutoff_p ? cutoff_p[0] : 0.0f;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
         const int ci = i % cin;
         const int t = (i / cin) % taps;
         const int c = i / (cin * taps);
-        wq[i] = quantize_weight(kernel[((size_t)t * cin + ci) * cout + c], wkind, H, m);
+        wq[i] = quantize_weight(kernel[((size_t)t * cin + ci) * cout + c], wkind, H, m, cutoff);
     }
 }
 
@@ -932,9 +956,9 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
     QNN_REQUIRE(kh <= 3 && kw <= 3, QNN_EUNSUPPORTED,
                 "qnn_prepack_weights: kernel %dx%d larger than 3x3 is not supported", kh, kw);
     QNN_REQUIRE(stride >= 1, QNN_EINVAL, "qnn_prepack_weights: stride=%d", stride);
-    QNN_REQUIRE(wkind == QNN_W_FLOAT || wkind == QNN_W_BINARY || wkind == QNN_W_QUANT,
-                wkind == QNN_W_TERNARY ? QNN_EUNSUPPORTED : QNN_EINVAL,
-                "qnn_prepack_weights: wkind=%d not supported", wkind);
+    QNN_REQUIRE(wkind == QNN_W_FLOAT || wkind == QNN_W_BINARY || wkind == QNN_W_QUANT ||
+                    wkind == QNN_W_TERNARY,
+                QNN_EINVAL, "qnn_prepack_weights: wkind=%d not supported", wkind);
     QNN_REQUIRE(H > 0.0f, QNN_EINVAL, "qnn_prepack_weights: H=%g", (double)H);
     int wshift = 0;
     float m = 1.0f;
@@ -952,7 +976,7 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
             break;
         case QNN_STORE_I4:
         case QNN_STORE_I8:
-            QNN_REQUIRE((wkind == QNN_W_BINARY && H == 1.0f) ||
+            QNN_REQUIRE(((wkind == QNN_W_BINARY || wkind == QNN_W_TERNARY) && H == 1.0f) ||
                             (wkind == QNN_W_QUANT && wbits <= store),
                         QNN_EINVAL, "qnn_prepack_weights: wkind=%d wbits=%d does not fit %d-bit storage",
                         wkind, wbits, store);
@@ -985,8 +1009,12 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
     PREPACK_HIP(hipMalloc(&w->d_wq, nq * sizeof(float)));
     int grid = (int)((nq + kBlock - 1) / kBlock);
     if (grid > 4096) grid = 4096;
+    if (wkind == QNN_W_TERNARY) {
+        PREPACK_HIP(hipMalloc(&w->d_aux, 16));
+        hipLaunchKernelGGL(k_tern_cutoff, dim3(1), dim3(1024), 0, s, kernel, (int)nq, H, (float*)w->d_aux);
+    }
     hipLaunchKernelGGL(k_prepack_float, dim3(grid), dim3(kBlock), 0, s, kernel, w->d_wq, taps, cin,
-                       cout, wkind, H, m);
+                       cout, wkind, H, m, (const float*)w->d_aux);
     if (bias) {
         PREPACK_HIP(hipMalloc(&w->d_bias, cout * sizeof(float)));
         PREPACK_HIP(hipMemcpyAsync(w->d_bias, bias, cout * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1029,6 +1057,7 @@ extern "C" int qnn_free_weights(qnn_weights_t* w) {
     if (w->d_bias) (void)hipFree(w->d_bias);
     if (w->d_corr) (void)hipFree(w->d_corr);
     if (w->d_mfma_own) (void)hipFree(w->d_mfma_own);
+    if (w->d_aux) (void)hipFree(w->d_aux);
     delete w;
     return QNN_OK;
 }

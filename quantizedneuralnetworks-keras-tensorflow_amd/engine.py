@@ -21,6 +21,7 @@ import torch
 from . import _abi
 from .layers.binary_layers import BinaryConv2D, BinaryDense
 from .layers.quantized_layers import QuantizedConv2D, QuantizedDense
+from .layers.ternary_layers import TernaryConv2D, TernaryDense
 from .layers import binary_ops, quantized_ops, ternary_ops
 
 F32 = np.float32
@@ -36,13 +37,16 @@ def bn_constants(op):
 
 
 def _wkind(op):
-    return {"binary": _abi.W_BINARY, "quantized": _abi.W_QUANT, "float": _abi.W_FLOAT}[op["kind"]]
+    return {"binary": _abi.W_BINARY, "quantized": _abi.W_QUANT, "float": _abi.W_FLOAT,
+            "ternary": _abi.W_TERNARY}[op["kind"]]
 
 
 def _wstore(op):
     """Narrowest packed storage of a contraction's weights (None for float)."""
     if op["kind"] == "binary":
         return _abi.STORE_BIN
+    if op["kind"] == "ternary":
+        return _abi.STORE_I4                 # codes {-1, 0, 1}
     if op["kind"] == "quantized" and op["nb"] <= 8:
         return _abi.store_for_bits(op["nb"])
     return None
@@ -190,7 +194,9 @@ class _Virtual:
 
     def materialize(self):
         if self._mat is None:
-            if self.fn == _abi.FN_BINARY_TANH:
+            if self.fn == _abi.FN_GRID:             # already clipped (ternary_tanh): values ARE the grid
+                self._mat = self.pre
+            elif self.fn == _abi.FN_BINARY_TANH:
                 self._mat = binary_ops.binary_tanh(self.pre)
             else:
                 self._mat = quantized_ops.quantized_tanh(self.pre, self.nb)
@@ -266,12 +272,19 @@ class GraphModel:
                 wstore = _wstore(op)
                 if isinstance(src, _Virtual) and wstore is not None:
                     bits = 1 if src.fn == _abi.FN_BINARY_TANH else src.nb
-                    store = _join_store(bits, wstore)
+                    if src.fn == _abi.FN_GRID:       # ternary codes {-1,0,1}: value = code, needs >= 4 bits
+                        store = max(_abi.STORE_I4, wstore if wstore != _abi.STORE_BIN else _abi.STORE_I4)
+                    else:
+                        store = _join_store(bits, wstore)
                     pre = src.pre
                     C = pre.shape[-1]
                     w = self._get_weights(i, op, store)
                     nb_in = src.nb if src.fn == _abi.FN_QUANTIZED_TANH else 1
-                    if kind == "conv":
+                    if kind == "conv" and src.fn == _abi.FN_GRID:
+                        N, H, W, _ = pre.shape
+                        xp = _abi.pack(pre, C, _abi.FN_GRID, 1, store)
+                        y, _, _ = _abi.conv2d(w, xp, store, 1, N, H, W, inv, shift)
+                    elif kind == "conv":
                         # activation clip fused on load, BN fused in the epilogue
                         y, _, _ = _abi.conv2d_f32in(w, pre, src.fn, nb_in, inv, shift)
                     else:
@@ -301,7 +314,9 @@ class GraphModel:
                 elif fn == "quantized_tanh":
                     y = quantized_ops.quantized_tanh(pre, op["nb"])
                 elif fn == "ternary_tanh":
-                    y = ternary_ops.ternary_tanh(pre)
+                    # global mean over the batch tensor (ternary_ops.py:23): not fusable; the
+                    # result is on the grid {-1,0,1} and is packed as such by its consumers
+                    y = _Virtual(ternary_ops.ternary_tanh(pre), _abi.FN_GRID, 1)
                 elif fn == "leaky_relu":
                     y = torch.where(pre >= 0, pre, pre * F32(op.get("alpha", 0.3)))
                 else:
@@ -523,6 +538,9 @@ class ResidualFusedModel:
                         out = quantized_ops.quantized_tanh(pre, op["nb"])
                     elif fnn == "ternary_tanh":
                         out = ternary_ops.ternary_tanh(pre)
+                        tstore = self._act_out_store(name, 4)      # codes {-1,0,1}: at least 4-bit storage
+                        if tstore is not None:
+                            out = _Packed(_abi.pack(out, out.shape[-1], _abi.FN_GRID, 1, tstore), tstore, 1, out.shape)
                     elif fnn == "leaky_relu":
                         out = torch.where(pre >= 0, pre, pre * F32(op.get("alpha", 0.3)))
                     else:
@@ -588,7 +606,7 @@ class ResidualFusedModel:
 def _ok_lowbit(op):
     """Convs the fused epilogue path takes: low-bit weights (packed input) or the float-input
     first layer; stock float convs stay on the float32 route."""
-    return op["op"] == "conv" and op["kind"] in ("binary", "quantized") and op.get("nb", 1) <= 8
+    return op["op"] == "conv" and op["kind"] in ("binary", "quantized", "ternary") and op.get("nb", 1) <= 8
 
 
 # ---------------------------------------------------------------------------
@@ -614,6 +632,8 @@ class LayerModel:
                     layer = BinaryConv2D(cout, H=1., **kw)
                 elif op["kind"] == "quantized":
                     layer = QuantizedConv2D(cout, H=1., nb=op["nb"], **kw)
+                elif op["kind"] == "ternary":
+                    layer = TernaryConv2D(cout, H=1., **kw)
                 else:
                     raise _abi.QnnError("LayerModel covers the low-bit layers only")
                 layer.build((None, None, None, cin))
@@ -623,6 +643,8 @@ class LayerModel:
                     layer = BinaryDense(cout, **kw)
                 elif op["kind"] == "quantized":
                     layer = QuantizedDense(cout, nb=op["nb"], **kw)
+                elif op["kind"] == "ternary":
+                    layer = TernaryDense(cout, **kw)
                 else:
                     raise _abi.QnnError("LayerModel covers the low-bit layers only")
                 layer.build((None, cin))
@@ -661,6 +683,7 @@ class LayerModel:
                         d = ("quantized", op["nb"]) if op["nb"] <= 8 else None
                     elif op["fn"] == "ternary_tanh":
                         y = ternary_ops.ternary_tanh(src)
+                        d = ("quantized", 1)          # grid {-1,0,1}: value = code
                     else:
                         y = torch.where(src >= 0, src, src * F32(op.get("alpha", 0.3)))
                 elif kind == "maxpool":

@@ -144,7 +144,12 @@ class LowBitLayer:
         dom = self.input_domain
         if dom is None or dom == "float":
             return None
-        wbits_store = _abi.STORE_BIN if self._wkind == _abi.W_BINARY else _abi.store_for_bits(self._wbits())
+        if self._wkind == _abi.W_BINARY:
+            wbits_store = _abi.STORE_BIN
+        elif self._wkind == _abi.W_TERNARY:
+            wbits_store = _abi.STORE_I4          # codes {-1, 0, 1}
+        else:
+            wbits_store = _abi.store_for_bits(self._wbits())
         if dom == "binary" or dom == ("binary_tanh",) or dom == "binary_tanh":
             fn = _abi.FN_GRID if dom == "binary" else _abi.FN_BINARY_TANH
             store = _abi.STORE_BIN if wbits_store == _abi.STORE_BIN else wbits_store

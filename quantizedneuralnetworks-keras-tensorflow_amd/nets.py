@@ -79,8 +79,14 @@ def _layer_kinds(cf):
             act = {"op": "act", "fn": "quantized_tanh", "nb": cf.abits}
         else:
             act = {"op": "act", "fn": "binary_tanh"}
-    elif nt in ("tnn", "qtnn", "full-tnn"):
-        raise NotImplementedError("ternary layers are a 'next' row (SURVEY.md 8f.3)")
+    elif nt in ("tnn", "qtnn", "full-tnn"):      # model_factory.py:49-58
+        conv, fc = ("ternary", None), ("ternary", None)
+        if nt == "tnn":
+            act = {"op": "act", "fn": "leaky_relu", "alpha": 0.3}
+        elif nt == "qtnn":
+            act = {"op": "act", "fn": "quantized_tanh", "nb": cf.abits}
+        else:
+            act = {"op": "act", "fn": "ternary_tanh"}
     else:
         raise ValueError("wrong network type, the supported network types in this repo are "
                          "float, qnn, full-qnn, bnn and full-bnn")
@@ -117,6 +123,8 @@ class _ParamGen:
 def _w_var(kind, nb):
     if kind == "binary":
         return 1.0
+    if kind == "ternary":
+        return 0.65                 # U(-1,1) weights, cutoff 0.35: P(|w|=1) ~ 0.65
     if kind == "quantized":
         m = 2.0 ** (nb - 1)
         return ((2 * m) ** 2 - 1) / 12.0 / (m * m)
@@ -130,6 +138,8 @@ def _act_second_moment(act):
         return 1.0
     if act["fn"] == "quantized_tanh":
         return 0.45                 # ~N(0,1) clipped to [-1,1)
+    if act["fn"] == "ternary_tanh":
+        return 0.6
     return 0.6
 
 

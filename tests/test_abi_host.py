@@ -92,6 +92,20 @@ def test_dense_ctor_surface_and_weights_roundtrip():
 def test_aliases():
     assert qnn_amd.BinaryConvolution2D is qnn_amd.BinaryConv2D
     assert qnn_amd.QuantizedConvolution2D is qnn_amd.QuantizedConv2D
+    assert qnn_amd.TernaryConvolution2D is qnn_amd.TernaryConv2D
+
+
+def test_ternary_ctor_surface():
+    # ternary_layers.py:37-41,100-106
+    t = qnn_amd.TernaryConv2D(32, kernel_size=(3, 3), padding="same", H=1., device="cpu")
+    t.build((None, 8, 8, 16))
+    assert tuple(t.kernel.shape) == (3, 3, 16, 32) and t.kernel_lr_multiplier == np.float32(1. / np.sqrt(1.5 / (144 + 288)))
+    d = qnn_amd.TernaryDense(10, device="cpu")
+    d.build((None, 64))
+    assert set(d.get_config()) >= {"H", "kernel_lr_multiplier", "bias_lr_multiplier", "units"}
+    for nt in ("tnn", "qtnn", "full-tnn"):
+        spec = nets.build_spec(nets.Config(network_type=nt, architecture="VGG"), 1)
+        assert all(op["kind"] == "ternary" for op in spec if op["op"] in ("conv", "dense"))
 
 
 def test_baseline_specs_shapes():

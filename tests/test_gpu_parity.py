@@ -532,6 +532,54 @@ def test_residual_fused_model_runs_vgg_too(idx):
                                   O.run_spec(spec, x, float_conv="device"))
 
 
+@pytest.mark.parametrize("in_act", [BIN_ACT, Q(4), Q(8), None])
+def test_ternary_layers(in_act):
+    """TernaryConv2D / TernaryDense (ternary_layers.py:77-84,156-174): weights ternarised with the
+    global 0.7*mean|W| cutoff at prepack time."""
+    rng = np.random.default_rng(21)
+    pre = rng.standard_normal((2, 9, 9, 64)).astype(F32)
+    x = O.run_spec([in_act], pre) if in_act is not None else pre
+    k = rng.uniform(-1, 1, (3, 3, 64, 32)).astype(F32)
+    b = (rng.standard_normal(32) * 0.05).astype(F32)
+    layer = qnn_amd.TernaryConv2D(32, kernel_size=(3, 3), padding="same")
+    layer.build((None, 9, 9, 64))
+    layer.set_weights([k, b])
+    np.testing.assert_array_equal(host(layer.quantized_kernel()), O._ternarize(k))
+    np.testing.assert_array_equal(O._ternarize(k), O.ternarize(k))       # straight-through form is exact here
+    want = O.run_spec([{"op": "conv", "kind": "ternary", "kernel": k, "bias": b}], x)
+    if in_act is not None:
+        layer.input_domain = "binary" if in_act is BIN_ACT else ("quantized", in_act["nb"])
+        np.testing.assert_array_equal(host(layer(dev(x))), want)
+    else:
+        got = host(layer(dev(x)))
+        assert np.all(np.abs(got.astype(np.float64) - want) <= 1e-5 * np.maximum(1, np.abs(want)) * 4)
+    dk = rng.uniform(-1, 1, (64, 10)).astype(F32)
+    d = qnn_amd.TernaryDense(10)
+    d.build((None, 64))
+    d.set_weights([dk, np.zeros(10, F32)])
+    if in_act is not None:
+        d.input_domain = layer.input_domain
+        xv = x[:, 0, 0, :]
+        np.testing.assert_array_equal(host(d(dev(xv))), O.run_spec([{"op": "dense", "kind": "ternary", "kernel": dk,
+                                                                   "bias": np.zeros(10, F32)}], xv))
+
+
+@pytest.mark.parametrize("nt", ["tnn", "qtnn", "full-tnn"])
+@pytest.mark.parametrize("arch", ["VGG", "RESNET"])
+def test_ternary_networks(nt, arch):
+    """model_factory.py:49-58: ternary weights with LeakyReLU / quantized / ternary activations."""
+    cf = nets.Config(network_type=nt, wbits=4, abits=4, architecture=arch, nres=1, dim=32)
+    spec = nets.build_spec(cf, 31)
+    x = nets.synthetic_images(cf, 3, 31)
+    want = O.run_spec(spec, x, float_conv="device")
+    tol = 2e-5 if nt == "tnn" else 1e-6
+    for cls in (engine.GraphModel, engine.ResidualFusedModel, engine.LayerModel):
+        got = host(cls(spec)(dev(x)))
+        np.testing.assert_allclose(got, want, atol=tol, err_msg=cls.__name__)
+    if nt == "qtnn" and arch == "VGG":
+        np.testing.assert_array_equal(host(engine.FusedModel(spec)(dev(x))), want)
+
+
 def test_mnist_resnet_zero_padding():
     cf = nets.Config(network_type="full-bnn", architecture="RESNET", dataset="MNIST", dim=28,
                      channels=1, nres=1)
