@@ -267,6 +267,63 @@ def build_spec(cf, seed=0):
     raise ValueError("Error: type " + str(cf.architecture) + " is not supported")
 
 
+class Model:
+    """What models/model_factory.py:18-72 build_model(cf) hands to its callers (train.py:163-169,
+    test_resnet.py:63-81), reduced to the inference surface: predict / evaluate / summary /
+    set of weights, executing on the fused GPU engines."""
+
+    def __init__(self, cf, spec, device="cuda"):
+        from . import engine
+        self.cf, self.spec = cf, spec
+        try:
+            self.engine = engine.FusedModel(spec, device)          # chains (VGG)
+        except Exception:
+            self.engine = engine.ResidualFusedModel(spec, device)   # residual / non-fusable topologies
+        self.layers = [op for op in spec if op["op"] in ("conv", "dense")]
+
+    def predict(self, x, batch_size=4096):
+        import torch
+        x = torch.as_tensor(np.ascontiguousarray(x, dtype=F32))
+        outs = []
+        for i in range(0, x.shape[0], batch_size):
+            outs.append(self.engine(x[i:i + batch_size].cuda()).cpu())
+        return torch.cat(outs).numpy()
+
+    def evaluate(self, x, y, batch_size=4096):
+        """Top-1 accuracy; y is one-hot (or +-1 hinge targets, utils/load_data.py:84-88) or class ids."""
+        p = self.predict(x, batch_size)
+        y = np.asarray(y)
+        labels = y.argmax(-1) if y.ndim == 2 else y
+        return float((p.argmax(-1) == labels).mean())
+
+    def count_params(self):
+        n = 0
+        for op in self.spec:
+            for k in ("kernel", "bias", "gamma", "beta", "mean", "var"):
+                if op.get(k) is not None:
+                    n += int(np.asarray(op[k]).size)
+        return n
+
+    def summary(self, print_fn=print):
+        print_fn("%-4s %-10s %-28s %s" % ("#", "op", "detail", "params"))
+        for i, op in enumerate(self.spec):
+            d = ""
+            if op["op"] in ("conv", "dense"):
+                d = "%s %s%s" % (op["kind"], tuple(op["kernel"].shape), " nb=%d" % op["nb"] if "nb" in op else "")
+            elif op["op"] == "act":
+                d = op["fn"] + (" nb=%d" % op["nb"] if "nb" in op else "")
+            p = sum(int(np.asarray(op[k]).size) for k in ("kernel", "bias", "gamma", "beta", "mean", "var")
+                    if op.get(k) is not None)
+            print_fn("%-4d %-10s %-28s %d" % (i, op["op"], d, p))
+        print_fn("Total params: %d   engine: %s" % (self.count_params(), type(self.engine).__name__))
+
+
+def build_model(cf, seed=0, device="cuda"):
+    """model_factory.py:18-72: config -> model (synthetic weights; use spec_from_keras_npz +
+    Model(cf, spec) to run an imported checkpoint)."""
+    return Model(cf, build_spec(cf, seed), device)
+
+
 def synthetic_images(cf, n, seed=0):
     """uint8 U{0..255} / 255 as float32 NHWC (utils/load_data.py:40)."""
     rng = np.random.default_rng(seed)

@@ -580,6 +580,22 @@ def test_ternary_networks(nt, arch):
         np.testing.assert_array_equal(host(engine.FusedModel(spec)(dev(x))), want)
 
 
+def test_build_model_predict_evaluate():
+    cf = nets.baseline_config(2)
+    model = nets.build_model(cf, nets.SEED_BASE + 2)
+    assert type(model.engine).__name__ == "FusedModel" and model.count_params() > 80000
+    x = nets.synthetic_images(cf, 10, 4)
+    p = model.predict(x, batch_size=4)
+    np.testing.assert_array_equal(p, O.run_spec(model.spec, x, float_conv="device"))
+    acc = model.evaluate(x, np.eye(10, dtype=F32)[p.argmax(-1)])
+    assert acc == 1.0
+    lines = []
+    model.summary(lines.append)
+    assert "Total params" in lines[-1]
+    rmodel = nets.build_model(nets.Config(architecture="RESNET", nres=1), 3)
+    assert type(rmodel.engine).__name__ == "ResidualFusedModel"
+
+
 def test_mnist_resnet_zero_padding():
     cf = nets.Config(network_type="full-bnn", architecture="RESNET", dataset="MNIST", dim=28,
                      channels=1, nres=1)
