@@ -219,7 +219,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const long tile = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share
+    // an L2), so give each XCD a contiguous range of M-tiles: neighbouring tiles share their
+    // halo rows (and all of them the weights) in that XCD's L2.  Bijective for any grid size.
+    long tile;
+    {
+        const unsigned nb_ = gridDim.x, b_ = blockIdx.x;
+        const unsigned q_ = nb_ / 8, r_ = nb_ % 8, xcd = b_ % 8, idx = b_ / 8;
+        tile = (mg.ablate & 4) ? (long)b_
+                               : (long)((xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx);
+    }
     const int nbase = blockIdx.y * BN;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -337,11 +346,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
                 fa[t] = *reinterpret_cast<const v4i*>(smem + fa_addr[t][kk] + bufoff_a);
                 fb[t] = *reinterpret_cast<const v4i*>(smem + fb_addr[t][kk] + bufoff_b);
             }
+            if (!(mg.ablate & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            if (!(mg.ablate & 8)) __builtin_amdgcn_s_setprio(0);
         }
     };
 
