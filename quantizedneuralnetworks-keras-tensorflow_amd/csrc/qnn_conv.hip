@@ -24,6 +24,10 @@
 
 #include "qnn_common.h"
 
+#ifndef QNN_XNOR_U
+#define QNN_XNOR_U 16
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
     const int groups = (row_hi - row_lo + 1) * g.W * PAIRS;     // 64-channel groups to convert
     const float* xin = x + ((size_t)n * g.H + row_lo) * g.W * g.cin;
     uint2* tdst = tile + (size_t)(row_lo - (r0 - 1)) * g.W * PAIRS;
-    constexpr int U = 16;      // loads in flight per lane: phase 1 is latency-bound otherwise
+    constexpr int U = QNN_XNOR_U;      // loads in flight per lane: phase 1 is latency-bound otherwise
     for (int gi = wave * U; gi < groups; gi += 4 * U) {
         float v[U];
 #pragma unroll

@@ -26,6 +26,9 @@
 #include <type_traits>
 
 #include "qnn_common.h"
+#ifndef QNN_FIRST_WPS
+#define QNN_FIRST_WPS 3
+#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -443,6 +446,414 @@ int launch_out(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_
     return 1;
 }
 
+// folded per-lane epilogue constants and exact float packing (used by the persistent kernels)
+struct FoldEpi {
+    float nb, ninv, nshift;   // (+-)bias, (+-)inv * m, shift * m
+};
+
+__device__ __forceinline__ float max4(float a, float b, float c, float d) {
+    // v_maximum3_f32 x2 (NaN-propagating, no canonicalisation moves)
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b),
+                                         __builtin_elementwise_maximum(c, d));
+}
+
+// NV pre-scaled post-BN values (t * m) of one lane -> offset-coded fields of OBITS bits
+template <int OBITS, int NV>
+__device__ __forceinline__ uint32_t pack_scaled(const float* tm, float m, bool binary) {
+    constexpr int FPER = 16 / OBITS;                 // fields per exact 16-bit half
+    static_assert(NV % FPER == 0 && NV * OBITS <= 32, "fields must fill whole halves of one word");
+    constexpr int OFFSUM = (1 << (OBITS - 1)) * (OBITS == 4 ? 0x1111 : 0x0101);
+    float c[NV];
+    if (binary) {
+        asm volatile("; binary_tanh codes");         // keeps this a real (uniform) branch
+#pragma unroll
+        for (int j = 0; j < NV; ++j) c[j] = tm[j] > 0x1p-24f ? 1.0f : -1.0f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) c[j] = __builtin_amdgcn_fmed3f(rintf(tm[j]), -m, m - 1.0f);
+    }
+    uint32_t word = 0;
+#pragma unroll
+    for (int h = 0; h < NV / FPER; ++h) {
+        float S = (float)OFFSUM;
+#pragma unroll
+        for (int j = 0; j < FPER; ++j) S = __fmaf_rn(c[h * FPER + j], (float)(1 << (OBITS * j)), S);
+        word |= (uint32_t)S << (16 * h);
+    }
+    return word;
+}
+
+// ---------------------------------------------------------------------------------
+// Weight-resident persistent variant for short-K layers (Cout slice of 64, K = kh*kw*cin
+// small enough that the slice's whole int8 weight image fits in LDS beside two A buffers).
+//
+// k_conv_mfma above pays, per 256x64 output tile, a cold prologue (two K-steps of global
+// latency) and an epilogue nothing overlaps with; at K = 576 (9 steps) that is most of a
+// tile's lifetime (measured: 22 % of the int8 matrix peak on the CIFAR B0 layer).  Here a
+// workgroup stays resident, loads its 64 filters into LDS ONCE (all K-steps, same
+// swizzled 64-byte rows), and walks its M-tiles as ONE continuous K-step stream: the
+// two-deep register prefetch runs across tile boundaries, so the loads of the next tile
+// are in flight while the current tile finishes and is stored, and a step stages only the
+// A tile.  Two workgroups per CU (2 x (32 KB A + S*4 KB B)) interleave: one's epilogue
+// VALU runs under the other's MFMAs.
+//
+// Streams: the LOAD stream (l_*) is two K-steps ahead of the COMPUTE stream (c_*); each has
+// its own (tile, step) position; the per-row offsets / tap masks belong to the load stream
+// and are recomputed when it enters a new tile.  Tiles are dealt so that every XCD (L2)
+// owns a contiguous range of M-tiles.
+template <int XS, int OUT, int POOL>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma_wres(MfmaGeom mg, EpiArgs e,
+                                                           const uint8_t* __restrict__ x,
+                                                           const uint8_t* __restrict__ wq8,
+                                                           void* __restrict__ y, int ntiles) {
+    constexpr int BM = 256, RPP = 64, NA = 4;
+    constexpr int XCH = (XS == QNN_STORE_I8) ? 16 : 8;     // stored bytes per 16-channel chunk
+    constexpr int A_BUF = BM * 64;
+    constexpr int ROWTAB = 2 * A_BUF;                       // two tables of 256 x (offset, mask)
+    constexpr int B_BASE = ROWTAB + 2 * BM * 8;
+    constexpr int B_STEP = 64 * 64;                         // one K-step of the 64-filter slice
+    constexpr int MAXS = 12;
+    constexpr bool PACKED = OUT == QNN_STORE_I4 || OUT == QNN_STORE_I8;
+    const ConvGeom& g = mg.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = mg.steps;
+    const int ntaps = g.kh * g.kw;
+    const int nbase = blockIdx.y * 64;
+
+    // tiles of this workgroup: XCD x owns [x*per_xcd, (x+1)*per_xcd), its workgroups interleave
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t_stride = gridDim.x >> 3;                    // grid.x is a multiple of 8
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int t_begin = xcd * per_xcd + idx;
+    const int t_end = min((xcd + 1) * per_xcd, ntiles);
+    if (t_begin >= t_end) return;                           // uniform per workgroup
+    const int my_tiles = (t_end - t_begin + t_stride - 1) / t_stride;
+    const int total = my_tiles * S;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(x), 0, (int)mg.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
+
+    const int srow = tid >> 2, sch = tid & 3;
+    // ---- the slice's filters -> LDS, all K-steps (issued together, written below) ----
+    uint4 wreg[MAXS];
+    {
+        const int w_row_bytes = ntaps * g.cin;
+        const int wv = (nbase + srow) * w_row_bytes + sch * 16;
+#pragma unroll
+        for (int st = 0; st < MAXS; ++st)
+            if (st < S) {
+                const int tap = st / mg.kc, kcc = st - tap * mg.kc;
+                wreg[st] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         wrsrc, wv, tap * g.cin + kcc * 64, 0));
+            }
+    }
+
+    // ---- per-lane epilogue constants (power-of-two factors folded, see k_conv_first_lds):
+    //      t*m = (v + bias/scale) * (inv*scale*m) + shift*m ----
+    const bool binary = e.fn == QNN_FN_BINARY_TANH;
+    const float mfold = (PACKED && !binary) ? e.act_m : 1.0f;
+    LaneEpi ke[2];
+    FoldEpi fe[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        lane_epi_init<OUT>(ke[b], e, nbase + b * 32 + li, li);
+        fe[b].nb = __fdiv_rn(ke[b].bias, e.scale);
+        fe[b].ninv = __fmul_rn(__fmul_rn(ke[b].inv, e.scale), mfold);
+        fe[b].nshift = __fmul_rn(ke[b].shift, mfold);
+    }
+    int lane_off = 0, lane_row = 0;       // packed outputs: word offset / local row of this lane's word
+    if constexpr (OUT == QNN_STORE_I4) {
+        const int jl = li & 7;
+        lane_row = (POOL == 2) ? wm * 16 + 2 * (jl & 3) + lh + 8 * (jl >> 2)
+                               : wm * 64 + (jl & 3) + 8 * (jl >> 2) + 4 * lh;
+        lane_off = lane_row * e.ocw + ((nbase + li) >> 3);
+    } else if constexpr (OUT == QNN_STORE_I8) {
+        const int jl = li & 3;
+        lane_row = (POOL == 2) ? wm * 16 + 2 * jl + lh : wm * 64 + jl + 4 * lh;
+        lane_off = lane_row * e.ocw + ((nbase + li) >> 2);
+    }
+
+    // ---- row table: thread r computes (byte offset of the receptive field's top-left pixel,
+    // 9-bit "tap inside the image" mask) of tile row r once; the four threads that stage
+    // a row read it back from LDS ----
+    auto row_compute = [&](int tile, int par) {
+        const int R = tid;
+        long q;
+        int sub = 0;
+        if constexpr (POOL == 2) { q = (long)tile * (BM / 4) + (R >> 2); sub = R & 3; }
+        else q = (long)tile * BM + R;
+        uint32_t m = 0;
+        int voff = 0;
+        if (tile < t_end && q < mg.total_q) {
+            const uint32_t qrow = qnn_div((uint32_t)q, g.fd_wp);
+            const int px = (int)((uint32_t)q - qrow * g.Wp);
+            const int n = (int)qnn_div(qrow, g.fd_hp);
+            const int py = (int)(qrow - (uint32_t)n * g.Hp);
+            const int iy0 = (py * POOL + (sub >> 1)) * g.stride - g.pt;
+            const int ix0 = (px * POOL + (sub & 1)) * g.stride - g.pl;
+            voff = ((n * g.H + iy0) * g.W + ix0) * mg.x_pix_bytes;
+            // taps [lo, hi) of a row / column lie inside the image; mask = outer product
+            const int xlo = max(0, -ix0), xhi = min(g.kw, g.W - ix0);
+            const int ylo = max(0, -iy0), yhi = min(g.kh, g.H - iy0);
+            const uint32_t cm = xhi > xlo ? ((1u << xhi) - 1u) & ~((1u << xlo) - 1u) : 0u;
+            for (int dy = ylo; dy < yhi; ++dy) m |= cm << (dy * g.kw);
+        }
+        *reinterpret_cast<uint2*>(smem + ROWTAB + par * (BM * 8) + R * 8) = make_uint2((uint32_t)voff, m);
+    };
+    int a_voff[NA];
+    uint32_t a_mask[NA];
+    auto row_fetch = [&](int par) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const uint2 v = *reinterpret_cast<const uint2*>(smem + ROWTAB + par * (BM * 8) + (srow + p * RPP) * 8);
+            a_voff[p] = (int)v.x + sch * XCH;
+            a_mask[p] = v.y;
+        }
+    };
+    int a_lds[NA];
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+        const int R = srow + p * RPP;
+        a_lds[p] = R * 64 + ((sch ^ ((R >> 2) & 3)) << 4);
+    }
+
+    // ---- load stream ----
+    int l_tile = t_begin, l_par = 0, l_tap = 0, l_kc = 0, l_dy = 0, l_dx = 0;
+    using araw_t = typename std::conditional<XS == QNN_STORE_I8, uint4, uint2>::type;
+    araw_t raA[NA], raB[NA];
+    auto stage_load = [&](araw_t (&ra)[NA]) {
+        const int xoff = (l_dy * g.W + l_dx) * mg.x_pix_bytes + l_kc * (4 * XCH);
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const bool ok = (a_mask[p] >> l_tap) & 1u;
+            const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;   // out of range -> zeros
+            if constexpr (XS == QNN_STORE_I8)
+                ra[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
+            else
+                ra[p] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0));
+        }
+        if (++l_kc == mg.kc) {
+            l_kc = 0; ++l_tap;
+            if (++l_dx == g.kw) { l_dx = 0; ++l_dy; }
+            if (l_tap == ntaps) {                  // the load stream enters the next tile:
+                l_tap = 0; l_dy = 0; l_dx = 0;     // its rows were tabulated one tile ago (at least
+                l_tile += t_stride;                // one barrier back); tabulate the one after it
+                l_par ^= 1;
+                row_fetch(l_par);
+                row_compute(l_tile + t_stride, l_par ^ 1);
+            }
+        }
+    };
+    auto stage_write = [&](const araw_t (&ra)[NA], int bufoff) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            uint4 v;
+            if constexpr (XS == QNN_STORE_I8) v = ra[p];
+            else v = make_uint4((ra[p].x << 4) & 0xF0F0F0F0u, ra[p].x & 0xF0F0F0F0u,
+                                (ra[p].y << 4) & 0xF0F0F0F0u, ra[p].y & 0xF0F0F0F0u);
+            *reinterpret_cast<uint4*>(smem + a_lds[p] + bufoff) = v;
+        }
+    };
+
+    // ---- fragment read addresses: [kk]; the second 32-row tile is +2048 bytes ----
+    int fa_addr[2], fb_addr[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ra_ = wm * 64 + li;
+        fa_addr[kk] = ra_ * 64 + (((kk * 2 + lh) ^ ((ra_ >> 2) & 3)) << 4);
+        fb_addr[kk] = B_BASE + li * 64 + (((kk * 2 + lh) ^ ((li >> 2) & 3)) << 4);
+    }
+
+    v16i acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+    // ---- compute stream ----
+    int c_tile = t_begin, c_ks = 0;
+    auto bn = [&](int v, const FoldEpi& f) {
+        return __fadd_rn(__fmul_rn(__fadd_rn((float)v, f.nb), f.ninv), f.nshift);
+    };
+    auto epilogue = [&]() {
+        const long tile = c_tile;
+        const long row0 = tile * (POOL == 2 ? BM / 4 : BM);          // first stored pixel of the tile
+        const long rem_l = mg.total_q - row0;
+        const int rem = rem_l > BM ? BM : (int)rem_l;                // stored pixels left from row0
+        uint32_t* ytile = reinterpret_cast<uint32_t*>(y) + row0 * e.ocw;   // packed outputs only
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = nbase + b * 32 + li;
+            if constexpr (POOL == 2) {
+                float t[8];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        // int -> float -> affine map is monotone: pool on the integer accumulators
+                        const int i0 = acc[a][b][4 * g4], i1 = acc[a][b][4 * g4 + 1];
+                        const int i2 = acc[a][b][4 * g4 + 2], i3 = acc[a][b][4 * g4 + 3];
+                        const int mx = max(max(i0, i1), max(i2, i3));
+                        const int mn = min(min(i0, i1), min(i2, i3));
+                        t[a * 4 + g4] = bn(ke[b].neg ? mn : mx, fe[b]);
+                    }
+                if constexpr (OUT == QNN_STORE_I4) {
+                    const uint32_t P = pack_scaled<4, 8>(t, e.act_m, binary);
+                    const uint32_t Wd = transpose_nib8(P, ke[0]) ^ 0x88888888u;
+                    if (lane_row < rem) ytile[lane_off + b * 4] = Wd;
+                } else if constexpr (OUT == QNN_STORE_I8) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const uint32_t P = pack_scaled<8, 4>(&t[4 * a], e.act_m, binary);
+                        const uint32_t Wd = transpose_byte4(P, ke[0]) ^ 0x80808080u;
+                        if (lane_row + 8 * a < rem) ytile[lane_off + 8 * a * e.ocw + b * 8] = Wd;
+                    }
+                } else {
+                    store_values<OUT, 8>(t, ke[b], e, li,
+                        [&](int j) { return row0 + (wm * 16 + (j >> 2) * 8 + 2 * (j & 3) + lh); },
+                        [&](int) { return c; }, mg.total_q, g.cout, y);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float t[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = bn(acc[a][b][r], fe[b]);
+                    if constexpr (OUT == QNN_STORE_I4) {
+#pragma unroll
+                        for (int gq = 0; gq < 2; ++gq) {
+                            const uint32_t P = pack_scaled<4, 8>(&t[8 * gq], e.act_m, binary);
+                            const uint32_t Wd = transpose_nib8(P, ke[0]) ^ 0x88888888u;
+                            const int dr = a * 32 + 16 * gq;
+                            if (lane_row + dr < rem) ytile[lane_off + dr * e.ocw + b * 4] = Wd;
+                        }
+                    } else if constexpr (OUT == QNN_STORE_I8) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const uint32_t P = pack_scaled<8, 4>(&t[4 * gq], e.act_m, binary);
+                            const uint32_t Wd = transpose_byte4(P, ke[0]) ^ 0x80808080u;
+                            const int dr = a * 32 + 8 * gq;
+                            if (lane_row + dr < rem) ytile[lane_off + dr * e.ocw + b * 8] = Wd;
+                        }
+                    } else {
+                        store_values<OUT, 16>(t, ke[b], e, li,
+                            [&](int j) { return row0 + wm * 64 + a * 32 + (j & 3) + 8 * (j >> 2) + 4 * lh; },
+                            [&](int) { return c; }, mg.total_q, g.cout, y);
+                    }
+                }
+            }
+        }
+    };
+    auto compute = [&](int bufoff) {
+        const int boff = c_ks * B_STEP;
+        const bool first = c_ks == 0;              // first K-step of a tile: C = 0
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v4i fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = *reinterpret_cast<const v4i*>(smem + fa_addr[kk] + bufoff + t * 2048);
+                fb[t] = *reinterpret_cast<const v4i*>(smem + fb_addr[kk] + boff + t * 2048);
+            }
+            __builtin_amdgcn_s_setprio(1);
+            if (kk == 0 && first) {
+                const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], z, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (++c_ks == S) {                         // tile finished: store it, start the next
+            epilogue();
+            c_ks = 0;
+            c_tile += t_stride;
+        }
+    };
+
+    // ---- prologue: row tables of the first two tiles, filters into LDS, steps 0 and 1 in flight ----
+    row_compute(t_begin, 0);
+    row_compute(t_begin + t_stride, 1);
+#pragma unroll
+    for (int st = 0; st < MAXS; ++st)
+        if (st < S)
+            *reinterpret_cast<uint4*>(smem + B_BASE + st * B_STEP + srow * 64 +
+                                      ((sch ^ ((srow >> 2) & 3)) << 4)) = wreg[st];
+    __syncthreads();
+    row_fetch(0);
+    stage_load(raA);
+    stage_load(raB);
+    stage_write(raA, 0);
+    __syncthreads();
+    int gs = 0;
+    for (; gs + 1 < total; gs += 2) {
+        stage_load(raA);                           // step gs+2 -> set A
+        compute(0);                                // step gs   (buffer 0)
+        stage_write(raB, A_BUF);                   // step gs+1 -> buffer 1
+        __syncthreads();
+        stage_load(raB);                           // step gs+3 -> set B
+        compute(A_BUF);                            // step gs+1 (buffer 1)
+        stage_write(raA, 0);                       // step gs+2 -> buffer 0
+        __syncthreads();
+    }
+    if (gs < total) compute(0);                    // odd number of steps: the last sits in buffer 0
+}
+
+template <int XS, int OUT>
+void launch_wres_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
+                      hipStream_t s) {
+    const long rows = mg.total_q * (mg.g.pool == 2 ? 4 : 1);
+    const int ntiles = (int)((rows + 255) / 256);
+    const int ny = mg.g.cout / 64;
+    int gx = ((ntiles + 7) / 8) * 8;
+    const int cap = ((512 / ny + 7) / 8) * 8;               // two resident workgroups per CU
+    if (gx > cap) gx = cap;
+    const dim3 grid((unsigned)gx, (unsigned)ny), block(256);
+    const size_t lds = 2 * 256 * 64 + 2 * 256 * 8 + (size_t)mg.steps * 64 * 64;
+    // more than 64 KB of dynamic LDS has to be allowed per kernel once
+    static const bool lds_ok = [] {
+        (void)hipFuncSetAttribute((const void*)k_conv_mfma_wres<XS, OUT, 2>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_conv_mfma_wres<XS, OUT, 1>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        return true;
+    }();
+    (void)lds_ok;
+    if (mg.g.pool == 2)
+        hipLaunchKernelGGL((k_conv_mfma_wres<XS, OUT, 2>), grid, block, lds, s, mg, e, (const uint8_t*)x, w, y, ntiles);
+    else
+        hipLaunchKernelGGL((k_conv_mfma_wres<XS, OUT, 1>), grid, block, lds, s, mg, e, (const uint8_t*)x, w, y, ntiles);
+}
+
+template <int XS>
+int launch_wres(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
+                hipStream_t s) {
+    switch (e.out_store) {
+        case QNN_STORE_F32: launch_wres_pool<XS, QNN_STORE_F32>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_BIN: launch_wres_pool<XS, QNN_STORE_BIN>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_I4: launch_wres_pool<XS, QNN_STORE_I4>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_I8: launch_wres_pool<XS, QNN_STORE_I8>(mg, e, x, w, y, s); return 0;
+    }
+    return 1;
+}
+
 // ---------------------------------------------------------------------------------
 // Float-input first layer on the float32 matrix pipe (v_mfma_f32_32x32x2_f32).
 // gfx950's f32 MFMA is bit-for-bit a k-ordered fmaf chain (one rounding per product,
@@ -574,17 +985,29 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 3 : 2)) void k_conv_first_mfma(Conv
 
 // ---------------------------------------------------------------------------------
 // Same layer, operands through LDS: every wave stages the float32 patch of its 32-pixel
-// tile (plus a zero halo) into a wave-private LDS tile with coalesced bounds-checked
-// buffer loads, and the lanes fetch their MFMA A operands with ds_read_b32 at
-// loop-invariant addresses -- the per-tap border logic and 64-bit address arithmetic of
-// the gather version disappear from the VALU stream (which is additive with the f32 MFMA).
-// Filters of channels with a negative BN scale are negated on load (exactly negating the
-// FMA chain), so max-pooling needs only v_max; the sign is restored before the epilogue.
+// tile (plus a zero halo) into a wave-private LDS tile with coalesced buffer loads, and
+// the lanes fetch their MFMA A operands with ds_read_b32 at loop-invariant addresses.
+//
+// The f32 MFMA shares the FMA datapath with the VALU (measured: the two do not overlap,
+// DESIGN.md 3.1), so every VALU instruction in this loop is paid in full.  Hence:
+//   * everything that depends only on the tile index lives in SGPRs (the wave index is
+//     read with readfirstlane, the tile decode is s_mul_hi arithmetic);
+//   * the zero halo is a scalar 64-bit lane mask per staging load: OR of the per-border
+//     masks (built once with ballots) selected by the tile's border flags, applied with
+//     one v_cndmask on the buffer offset (out-of-range offset -> the load returns 0.0f);
+//   * filters of channels with a negative BN scale are negated on load (exactly negating
+//     the FMA chain) so pooling is v_maximum3 only; the sign is folded back into the BN
+//     constants: ((-m + b) * inv) == ((m + (-b)) * (-inv)) bit for bit;
+//   * for packed outputs the power-of-two code scale 2^(bits-1) is folded into inv and
+//     shift (exact scaling), and the codes of one lane are assembled as an exact float
+//     sum  S = sum (code_j + off) * 2^(bits*j)  (< 2^16) with one v_fma per code and one
+//     v_cvt_u32 per 16 bits instead of cvt + shift + or per code.
 // Tiling: POOL==2: 8 pool windows in a row = conv rows 2*py..2*py+1 x 16 columns (needs
-// Wp % 8 == 0); POOL==1: 32 pixels in a row (needs W % 32 == 0).  No barriers: the LDS
-// tile is private to the wave.
+// Wp % 8 == 0); POOL==1: 32 pixels in a row (needs W % 32 == 0): tiles never straddle
+// the image edge, so no store needs a bounds check.  No barriers: the LDS tile is
+// private to the wave.
 template <int CIN, int NT, int OUT, int POOL>
-__global__ __launch_bounds__(256, 3) void k_conv_first_lds(ConvGeom g, EpiArgs e,
+__global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom g, EpiArgs e,
                                                            const float* __restrict__ x,
                                                            const float* __restrict__ wq,
                                                            void* __restrict__ y, long total_q,
@@ -596,40 +1019,52 @@ __global__ __launch_bounds__(256, 3) void k_conv_first_lds(ConvGeom g, EpiArgs e
     constexpr int TCOLS = (POOL == 2) ? 18 : 34;      // conv cols + halo
     constexpr int TE = TROWS * TCOLS * CIN;           // floats per tile
     constexpr int NJ = (TE + 63) / 64;                // staging loads per lane
+    constexpr bool PACKED = OUT == QNN_STORE_I4 || OUT == QNN_STORE_I8;
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     const int lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
-    const int wv = threadIdx.x >> 6;
-    float* lds = reinterpret_cast<float*>(smem_f) + wv * (2 * TE);   // two buffers per wave
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* lds = reinterpret_cast<float*>(smem_f) + wv * TE;          // wave-private tile
     const int wave_id = blockIdx.x * 4 + wv;
     const int nwaves = gridDim.x * 4;
     const int cbase = blockIdx.y * (NT * 32);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
+    const bool binary = e.fn == QNN_FN_BINARY_TANH;
+    const float mfold = (PACKED && !binary) ? e.act_m : 1.0f;
 
     // ---- per-lane constants ----
     LaneEpi ke[NT];
+    FoldEpi fe[NT];
     float wb[NT][KS];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         lane_epi_init<OUT>(ke[nt], e, cbase + nt * 32 + li, li);
+        const bool flip = POOL == 2 && ke[nt].neg;
+        fe[nt].nb = flip ? -ke[nt].bias : ke[nt].bias;
+        fe[nt].ninv = __fmul_rn(flip ? -ke[nt].inv : ke[nt].inv, mfold);
+        fe[nt].nshift = __fmul_rn(ke[nt].shift, mfold);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int k = 2 * s + lh;
             float w = k < K ? wq[(long)(cbase + nt * 32 + li) * K + k] : 0.0f;
-            wb[nt][s] = (POOL == 2 && ke[nt].neg) ? -w : w;
+            wb[nt][s] = flip ? -w : w;
         }
     }
     // staging: element ej = lane + 64*j of the [TROWS][TCOLS][CIN] tile
-    int st_goff[NJ], st_r[NJ], st_c[NJ];
+    int st_goff[NJ];
+    unsigned long long mX[NJ], mT[NJ], mB[NJ], mL[NJ], mR[NJ];   // lanes outside the tile / on each halo edge
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int ej = lane + 64 * j;
         const int r = ej / (TCOLS * CIN), rem = ej - r * (TCOLS * CIN);
         const int col = rem / CIN, ch = rem - col * CIN;
-        st_r[j] = (ej < TE) ? r : -100000;
-        st_c[j] = col;
         st_goff[j] = ((r * g.W + col) * CIN + ch) * 4;
+        mX[j] = __ballot(ej >= TE);
+        mT[j] = __ballot(r == 0);
+        mB[j] = __ballot(r == TROWS - 1);
+        mL[j] = __ballot(col == 0);
+        mR[j] = __ballot(col == TCOLS - 1);
     }
     // operand k = 2s+lh of this lane's pixel: LDS word index relative to the tile
     int lrow, lcol;
@@ -644,7 +1079,20 @@ __global__ __launch_bounds__(256, 3) void k_conv_first_lds(ConvGeom g, EpiArgs e
         op_idx[s] = ((lrow + tap / 3) * TCOLS + (lcol + tap % 3)) * CIN + ch;
     }
     const bool kpad = (K & 1) && lh == 1;          // lane half 1 of the last k-step is padding
+    // packed outputs: after the in-register transpose lane (li & 7) / (li & 3) of an octet /
+    // quad holds one finished word; its word offset from the tile's first stored pixel
+    int lane_off = 0;
+    if constexpr (OUT == QNN_STORE_I4) {
+        const int jl = li & 7;
+        lane_off = (POOL == 2) ? (2 * (jl & 3) + lh) * e.ocw + ((cbase + (jl >> 2) * 32 + li) >> 3)
+                               : ((jl & 3) + 8 * (jl >> 2) + 4 * lh) * e.ocw + ((cbase + li) >> 3);
+    } else if constexpr (OUT == QNN_STORE_I8) {
+        const int jl = li & 3;
+        lane_off = (POOL == 2) ? (2 * jl + lh) * e.ocw + ((cbase + li) >> 2)
+                               : (jl + 4 * lh) * e.ocw + ((cbase + li) >> 2);
+    }
 
+    // all scalar: t is wave-uniform
     auto tile_origin = [&](int t, int& n, int& oy0, int& ox0) {
         const uint32_t trow = qnn_div((uint32_t)t, fd_tpr);           // = n*rows + row
         const int tb = t - (int)trow * tiles_per_row;
@@ -660,40 +1108,48 @@ __global__ __launch_bounds__(256, 3) void k_conv_first_lds(ConvGeom g, EpiArgs e
         int n, oy0, ox0;
         tile_origin(t, n, oy0, ox0);
         const int base4 = (((n * g.H + (oy0 - 1)) * g.W + (ox0 - 1)) * CIN) * 4;
+        const bool top = oy0 == 0, bot = oy0 + (TROWS - 2) == g.H;
+        const bool left = ox0 == 0, right = ox0 + (TCOLS - 2) == g.W;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const bool ok = (unsigned)(oy0 - 1 + st_r[j]) < (unsigned)g.H &&
-                            (unsigned)(ox0 - 1 + st_c[j]) < (unsigned)g.W;
-            const int voff = ok ? base4 + st_goff[j] : (int)0x80000000;      // out of range -> 0.0f (the halo)
+            const unsigned long long m = mX[j] | (top ? mT[j] : 0ull) | (bot ? mB[j] : 0ull) |
+                                         (left ? mL[j] : 0ull) | (right ? mR[j] : 0ull);
+            const bool halo = __builtin_amdgcn_inverse_ballot_w64(m);
+            const int voff = halo ? (int)0x80000000 : base4 + st_goff[j];   // out of range -> 0.0f
             stg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, 0, 0));
         }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](int) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (lane + 64 * j < TE) lds[buf * TE + lane + 64 * j] = stg[j];
+            if (lane + 64 * j < TE) lds[lane + 64 * j] = stg[j];
     };
 
+    // Order inside one iteration (tile i): MFMAs on the operands fetched during the previous
+    // iteration -> hand tile i+1 from the staging registers to LDS, fetch its operands, start
+    // the global loads of tile i+2 -> epilogue and store of tile i.  The s_waitcnt vmcnt(0)
+    // in front of the LDS hand-over (loads and stores share the counter on gfx9) then sits
+    // AFTER a whole MFMA phase, so neither the previous store's write acknowledge nor the
+    // load latency is exposed, and the operand fetch hides behind the epilogue.
     int t = wave_id;
     if (t >= tiles) return;
+    float av[KS];
+    auto fetch_operands = [&]() {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) av[s] = lds[op_idx[s]];
+    };
     stage_load(t);
     stage_write(0);
-    stage_load(min(t + nwaves, tiles - 1));        // unconditional (clamped): keeps the waits counted
-    int buf = 0;
+    fetch_operands();
+    stage_load(min(t + nwaves, tiles - 1));        // unconditional (clamped)
     for (; t < tiles; t += nwaves) {
-        // ---- A operands of this tile from LDS ----
-        float av[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) av[s] = lds[buf * TE + op_idx[s]];
-        if (kpad) av[KS - 1] = 0.0f;
-        // ---- hand the next tile to the other buffer, start the loads of the one after ----
-        stage_write(buf ^ 1);
-        stage_load(min(t + 2 * nwaves, tiles - 1));
         int n, oy0, ox0;
         tile_origin(t, n, oy0, ox0);
         // stored-pixel index of this tile's first window / pixel
         const long q_base = (POOL == 2) ? ((long)n * g.Hp + (oy0 >> 1)) * g.Wp + (ox0 >> 1)
                                         : ((long)n * g.H + oy0) * g.W + ox0;
+        uint32_t* ytile = reinterpret_cast<uint32_t*>(y) + q_base * e.ocw;   // packed outputs only
+        if (kpad) av[KS - 1] = 0.0f;
 #pragma unroll
         for (int nc = 0; nc < NT; nc += 2) {
             v16f acc[2];
@@ -706,33 +1162,67 @@ __global__ __launch_bounds__(256, 3) void k_conv_first_lds(ConvGeom g, EpiArgs e
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wb[nc + u][s], acc[u], 0, 0, 0);
+            if (nc + 2 >= NT) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_write(0);
+                fetch_operands();
+                stage_load(min(t + 2 * nwaves, tiles - 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            auto bn = [&](float v, const FoldEpi& f) {
+                return __fadd_rn(__fmul_rn(__fadd_rn(v, f.nb), f.ninv), f.nshift);
+            };
             if constexpr (POOL == 2) {
                 float tv[8];
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const float m = fmaxf(fmaxf(acc[u][4 * g4], acc[u][4 * g4 + 1]),
-                                              fmaxf(acc[u][4 * g4 + 2], acc[u][4 * g4 + 3]));
-                        tv[u * 4 + g4] = bn_apply(ke[nc + u].neg ? -m : m, ke[nc + u]);
-                    }
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        tv[u * 4 + g4] = bn(max4(acc[u][4 * g4], acc[u][4 * g4 + 1], acc[u][4 * g4 + 2],
+                                                 acc[u][4 * g4 + 3]), fe[nc + u]);
                 // tile row R = 8*g4 + 4*lh + s is window R/4 = 2*g4 + lh
-                store_values<OUT, 8>(tv, ke[0], e, li,
-                    [&](int j) { return q_base + 2 * (j & 3) + lh; },
-                    [&](int j) { return cbase + (nc + (j >> 2)) * 32 + li; }, total_q, g.cout, y);
+                if constexpr (OUT == QNN_STORE_I4) {
+                    const uint32_t P = pack_scaled<4, 8>(tv, e.act_m, binary);
+                    ytile[lane_off + nc * 4] = transpose_nib8(P, ke[0]) ^ 0x88888888u;
+                } else if constexpr (OUT == QNN_STORE_I8) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint32_t P = pack_scaled<8, 4>(&tv[4 * u], e.act_m, binary);
+                        ytile[lane_off + (nc + u) * 8] = transpose_byte4(P, ke[0]) ^ 0x80808080u;
+                    }
+                } else {
+                    store_values<OUT, 8>(tv, ke[0], e, li,
+                        [&](int j) { return q_base + 2 * (j & 3) + lh; },
+                        [&](int j) { return cbase + (nc + (j >> 2)) * 32 + li; }, total_q, g.cout, y);
+                }
             } else {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     float tv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) tv[r] = bn_apply(acc[u][r], ke[nc + u]);
-                    store_values<OUT, 16>(tv, ke[nc + u], e, li,
-                        [&](int j) { return q_base + (j & 3) + 8 * (j >> 2) + 4 * lh; },
-                        [&](int) { return cbase + (nc + u) * 32 + li; }, total_q, g.cout, y);
+                    for (int r = 0; r < 16; ++r) tv[r] = bn(acc[u][r], fe[nc + u]);
+                    if constexpr (OUT == QNN_STORE_I4) {
+#pragma unroll
+                        for (int gq = 0; gq < 2; ++gq) {
+                            const uint32_t P = pack_scaled<4, 8>(&tv[8 * gq], e.act_m, binary);
+                            ytile[lane_off + 16 * gq * e.ocw + (nc + u) * 4] =
+                                transpose_nib8(P, ke[0]) ^ 0x88888888u;
+                        }
+                    } else if constexpr (OUT == QNN_STORE_I8) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const uint32_t P = pack_scaled<8, 4>(&tv[4 * gq], e.act_m, binary);
+                            ytile[lane_off + 8 * gq * e.ocw + (nc + u) * 8] =
+                                transpose_byte4(P, ke[0]) ^ 0x80808080u;
+                        }
+                    } else {
+                        store_values<OUT, 16>(tv, ke[nc + u], e, li,
+                            [&](int j) { return q_base + (j & 3) + 8 * (j >> 2) + 4 * lh; },
+                            [&](int) { return cbase + (nc + u) * 32 + li; }, total_q, g.cout, y);
+                    }
                 }
             }
         }
-        buf ^= 1;
     }
 }
 
@@ -761,11 +1251,11 @@ int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float
         const long ntiles = (long)g.N * rows * tpr;
         if (ntiles < 2.0e9) {
             long lblocks = (ntiles + 3) / 4;
-            const long lmax = 256 * 3 / ny;
+            const long lmax = 256 * QNN_FIRST_WPS / ny;   // persistent: QNN_FIRST_WPS waves per SIMD
             if (lblocks > lmax) lblocks = lmax;
             const dim3 lgrid((unsigned)lblocks, (unsigned)ny);
             const FastDiv fd_tpr = qnn_fastdiv((uint32_t)tpr);
-            const size_t lds_bytes = (size_t)4 * 2 * ((g.pool == 2 ? 4 * 18 : 3 * 34) * CIN) * 4;
+            const size_t lds_bytes = (size_t)4 * ((g.pool == 2 ? 4 * 18 : 3 * 34) * CIN) * 4;   // one tile per wave
 #define FIRST_LDS_CASE(OUT)                                                                      \
             if (e.out_store == OUT) {                                                            \
                 if (g.pool == 2)                                                                 \
@@ -874,6 +1364,16 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     if (tile_env && strlen(tile_env) == 3) {
         const int em = tile_env[0] - '0', en = tile_env[2] - '0';
         if (em >= 1 && en >= 1 && (g.cout % (64 * en)) == 0) { wm_ = em; wn_ = en; }
+    }
+    // short-K layers with one 64-filter slice: weight-resident persistent kernel
+    static const int wres_env = getenv("QNN_MFMA_WRES") ? atoi(getenv("QNN_MFMA_WRES")) : -1;
+    const long rows_ = mg.total_q * (g.pool == 2 ? 4 : 1);
+    const bool wres_fit = mg.steps <= 12 && rows_ < 2000000000L;
+    const bool wres = wres_env == 0 ? false : wres_env == 1 ? wres_fit : (wres_fit && g.cout == 64 && !tile_env);
+    if (wres) {
+        snprintf(name, name_len, "mfma_%s_wres256x64", x_store == QNN_STORE_I8 ? "i8" : "i4");
+        return x_store == QNN_STORE_I8 ? launch_wres<QNN_STORE_I8>(mg, e2, x, w->d_mfma, y, s)
+                                       : launch_wres<QNN_STORE_I4>(mg, e2, x, w->d_mfma, y, s);
     }
     snprintf(name, name_len, "mfma_%s_%dx%d", x_store == QNN_STORE_I8 ? "i8" : "i4", 64 * wm_, 64 * wn_);
 #define TILE_CASE(XS_, M_, N_) \
