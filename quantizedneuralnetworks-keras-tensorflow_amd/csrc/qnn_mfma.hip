@@ -816,6 +816,311 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_wres(MfmaGeom mg, EpiArgs 
     if (gs < total) compute(0);                    // odd number of steps: the last sits in buffer 0
 }
 
+// ---------------------------------------------------------------------------------
+// 3x3, Cin = 64*KC (KC <= 2): activations straight from global memory into MFMA operand
+// registers, filters resident in LDS, no barrier in the main loop.
+//
+// In v_mfma_i32_32x32x32_i8 lane l supplies A[row l&31][k = 16*(l>>5) .. +15]: sixteen
+// consecutive channels of ONE pixel = one 8-byte (int4) / 16-byte (int8) chunk of the
+// NHWC tensor.  So every lane can fetch exactly its own operand bytes with one buffer
+// load per (32-row tile, 32-deep k-block): the A tile never visits LDS, nothing is
+// shared between waves, and the only workgroup barrier is the one after the filter
+// slice has been written to LDS.  A wave owns a 64-row x 64-filter output tile (2x2
+// MFMA tiles) and walks its tiles as a continuous stream: K-steps fully unrolled (one
+// step = one tap x 64 channels), three rotating operand register sets, the loads of
+// step s+2 issued before the MFMAs of step s (also across the tile boundary: the next
+// tile's rows are decoded at step S-2), C = 0 on a tile's first step.
+// Zero padding: per tile and per (tap, 32-row tile) ONE 64-bit lane mask (ballot of "tap
+// inside the image" at row-decode time) kept in SGPRs and applied with a single
+// v_cndmask on the byte offset (out of range -> the buffer load returns zeros).
+// Three workgroups (12 waves) per CU: one wave's staging / epilogue VALU runs under
+// the other waves' MFMAs (int8 MFMA and VALU co-issue on gfx950).
+template <int XS, int OUT, int POOL, int KC>
+__global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs e,
+                                                           const uint8_t* __restrict__ x,
+                                                           const uint8_t* __restrict__ wq8,
+                                                           void* __restrict__ y, int ntiles) {
+    constexpr int TAPS = 9, S = TAPS * KC;
+    static_assert(S % 3 == 0, "operand register sets rotate with period 3");
+    constexpr int XCH = (XS == QNN_STORE_I8) ? 16 : 8;     // stored bytes per 16-channel chunk
+    constexpr int B_STEP = 64 * 64;                         // one K-step of the 64-filter slice
+    constexpr int TM = 64;                                  // rows per wave tile
+    constexpr int TQ = (POOL == 2) ? TM / 4 : TM;           // stored pixels per wave tile
+    constexpr bool PACKED = OUT == QNN_STORE_I4 || OUT == QNN_STORE_I8;
+    const ConvGeom& g = mg.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbase = blockIdx.y * 64;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(x), 0, (int)mg.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
+
+    // ---- the slice's filters -> LDS, all K-steps: rows of 64 bytes, chunks XOR-swizzled ----
+    {
+        const int srow = tid >> 2, sch = tid & 3;
+        const int w_row_bytes = TAPS * g.cin;
+        const int wv = (nbase + srow) * w_row_bytes + sch * 16;
+        uint4 wreg[S];
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+            wreg[st] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     wrsrc, wv, (st / KC) * g.cin + (st % KC) * 64, 0));
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+            *reinterpret_cast<uint4*>(smem + st * B_STEP + srow * 64 + ((sch ^ ((srow >> 2) & 3)) << 4)) = wreg[st];
+    }
+    __syncthreads();                                        // the only barrier
+
+    // tiles of this wave: XCD x owns [x*per_xcd, (x+1)*per_xcd), its waves interleave
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t_stride = (gridDim.x >> 3) * 4;              // grid.x is a multiple of 8
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int t_end = min((xcd + 1) * per_xcd, ntiles);
+    int t = xcd * per_xcd + idx * 4 + wave;
+    if (t >= t_end) return;
+
+    // ---- per-lane epilogue constants (power-of-two factors folded, see k_conv_first_lds) ----
+    const bool binary = e.fn == QNN_FN_BINARY_TANH;
+    const float mfold = (PACKED && !binary) ? e.act_m : 1.0f;
+    LaneEpi ke[2];
+    FoldEpi fe[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        lane_epi_init<OUT>(ke[b], e, nbase + b * 32 + li, li);
+        fe[b].nb = __fdiv_rn(ke[b].bias, e.scale);
+        fe[b].ninv = __fmul_rn(__fmul_rn(ke[b].inv, e.scale), mfold);
+        fe[b].nshift = __fmul_rn(ke[b].shift, mfold);
+    }
+    int lane_off = 0, lane_row = 0;       // packed outputs: word offset / local row of this lane's word
+    if constexpr (OUT == QNN_STORE_I4) {
+        const int jl = li & 7;
+        lane_row = (POOL == 2) ? 2 * (jl & 3) + lh + 8 * (jl >> 2) : (jl & 3) + 8 * (jl >> 2) + 4 * lh;
+        lane_off = lane_row * e.ocw + ((nbase + li) >> 3);
+    } else if constexpr (OUT == QNN_STORE_I8) {
+        const int jl = li & 3;
+        lane_row = (POOL == 2) ? 2 * jl + lh : jl + 4 * lh;
+        lane_off = lane_row * e.ocw + ((nbase + li) >> 2);
+    }
+
+    // ---- load stream: rows li and li+32 of the tile being fetched ----
+    int a_voff[2];
+    unsigned long long okm[TAPS][2];      // lanes whose tap is inside the image (SGPR pairs)
+    auto row_setup = [&](int tile) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int R = mt * 32 + li;
+            long q;
+            int sub = 0;
+            if constexpr (POOL == 2) { q = (long)tile * TQ + (R >> 2); sub = R & 3; }
+            else q = (long)tile * TQ + R;
+            uint32_t m = 0;
+            int voff = 0;
+            if (tile < t_end && q < mg.total_q) {
+                const uint32_t qrow = qnn_div((uint32_t)q, g.fd_wp);
+                const int px = (int)((uint32_t)q - qrow * g.Wp);
+                const int n = (int)qnn_div(qrow, g.fd_hp);
+                const int py = (int)(qrow - (uint32_t)n * g.Hp);
+                const int iy0 = (py * POOL + (sub >> 1)) * g.stride - g.pt;
+                const int ix0 = (px * POOL + (sub & 1)) * g.stride - g.pl;
+                voff = ((n * g.H + iy0) * g.W + ix0) * mg.x_pix_bytes + lh * XCH;
+                const int xlo = max(0, -ix0), xhi = min(3, g.W - ix0);
+                const int ylo = max(0, -iy0), yhi = min(3, g.H - iy0);
+                const uint32_t cm = xhi > xlo ? ((1u << xhi) - 1u) & ~((1u << xlo) - 1u) : 0u;
+                const uint32_t rm = yhi > ylo ? ((1u << yhi) - 1u) & ~((1u << ylo) - 1u) : 0u;
+                m = cm * ((rm & 1u) | ((rm & 2u) << 2) | ((rm & 4u) << 4));     // outer product
+            }
+            a_voff[mt] = voff;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) okm[tap][mt] = __ballot((m >> tap) & 1u);
+        }
+    };
+    using araw_t = typename std::conditional<XS == QNN_STORE_I8, uint4, uint2>::type;
+    araw_t R[3][2][2];                    // [set][32-row tile][k-block]
+    auto issue = [&](int st, araw_t (&r)[2][2]) {          // st = step within the tile (compile time)
+        const int tap = st / KC, kc = st % KC;
+        const int xoff = ((tap / 3) * g.W + (tap % 3)) * mg.x_pix_bytes + kc * (4 * XCH);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm[tap][mt]);
+            const int voff = ok ? a_voff[mt] + xoff : (int)0x80000000;   // out of range -> zeros
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (XS == QNN_STORE_I8)
+                    r[mt][kk] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff + kk * 2 * XCH, 0, 0));
+                else
+                    r[mt][kk] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff + kk * 2 * XCH, 0, 0));
+            }
+        }
+    };
+    auto operand = [&](const araw_t& r) -> v4i {
+        if constexpr (XS == QNN_STORE_I8) return __builtin_bit_cast(v4i, r);
+        else {
+            const uint4 v = make_uint4((r.x << 4) & 0xF0F0F0F0u, r.x & 0xF0F0F0F0u,
+                                       (r.y << 4) & 0xF0F0F0F0u, r.y & 0xF0F0F0F0u);
+            return __builtin_bit_cast(v4i, v);
+        }
+    };
+
+    // B fragment addresses: [kk]; the second 32-filter tile is +2048 bytes, a K-step +4096
+    int fb_addr[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fb_addr[kk] = li * 64 + (((kk * 2 + lh) ^ ((li >> 2) & 3)) << 4);
+
+    v16i acc[2][2];
+    auto bn = [&](int v, const FoldEpi& f) {
+        return __fadd_rn(__fmul_rn(__fadd_rn((float)v, f.nb), f.ninv), f.nshift);
+    };
+    auto epilogue = [&](int tile) {
+        const long row0 = (long)tile * TQ;                          // first stored pixel of the tile
+        const long rem_l = mg.total_q - row0;
+        const int rem = rem_l > TM ? TM : (int)rem_l;               // stored pixels left from row0
+        uint32_t* ytile = reinterpret_cast<uint32_t*>(y) + row0 * e.ocw;   // packed outputs only
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = nbase + b * 32 + li;
+            if constexpr (POOL == 2) {
+                float tv[8];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        // int -> float -> affine map is monotone: pool on the integer accumulators
+                        const int i0 = acc[a][b][4 * g4], i1 = acc[a][b][4 * g4 + 1];
+                        const int i2 = acc[a][b][4 * g4 + 2], i3 = acc[a][b][4 * g4 + 3];
+                        const int mx = max(max(i0, i1), max(i2, i3));
+                        const int mn = min(min(i0, i1), min(i2, i3));
+                        tv[a * 4 + g4] = bn(ke[b].neg ? mn : mx, fe[b]);
+                    }
+                if constexpr (OUT == QNN_STORE_I4) {
+                    const uint32_t P = pack_scaled<4, 8>(tv, e.act_m, binary);
+                    const uint32_t Wd = transpose_nib8(P, ke[0]) ^ 0x88888888u;
+                    if (lane_row < rem) ytile[lane_off + b * 4] = Wd;
+                } else if constexpr (OUT == QNN_STORE_I8) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const uint32_t P = pack_scaled<8, 4>(&tv[4 * a], e.act_m, binary);
+                        const uint32_t Wd = transpose_byte4(P, ke[0]) ^ 0x80808080u;
+                        if (lane_row + 8 * a < rem) ytile[lane_off + 8 * a * e.ocw + b * 8] = Wd;
+                    }
+                } else {
+                    store_values<OUT, 8>(tv, ke[b], e, li,
+                        [&](int j) { return row0 + ((j >> 2) * 8 + 2 * (j & 3) + lh); },
+                        [&](int) { return c; }, mg.total_q, g.cout, y);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float tv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tv[r] = bn(acc[a][b][r], fe[b]);
+                    if constexpr (OUT == QNN_STORE_I4) {
+#pragma unroll
+                        for (int gq = 0; gq < 2; ++gq) {
+                            const uint32_t P = pack_scaled<4, 8>(&tv[8 * gq], e.act_m, binary);
+                            const uint32_t Wd = transpose_nib8(P, ke[0]) ^ 0x88888888u;
+                            const int dr = a * 32 + 16 * gq;
+                            if (lane_row + dr < rem) ytile[lane_off + dr * e.ocw + b * 4] = Wd;
+                        }
+                    } else if constexpr (OUT == QNN_STORE_I8) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const uint32_t P = pack_scaled<8, 4>(&tv[4 * gq], e.act_m, binary);
+                            const uint32_t Wd = transpose_byte4(P, ke[0]) ^ 0x80808080u;
+                            const int dr = a * 32 + 8 * gq;
+                            if (lane_row + dr < rem) ytile[lane_off + dr * e.ocw + b * 8] = Wd;
+                        }
+                    } else {
+                        store_values<OUT, 16>(tv, ke[b], e, li,
+                            [&](int j) { return row0 + a * 32 + (j & 3) + 8 * (j >> 2) + 4 * lh; },
+                            [&](int) { return c; }, mg.total_q, g.cout, y);
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- main stream ----
+    row_setup(t);
+    issue(0, R[0]);
+    issue(1, R[1]);
+    for (; t < t_end; t += t_stride) {
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            if (st == S - 2) row_setup(t + t_stride);       // the load stream enters the next tile
+            issue((st + 2) % S, R[(st + 2) % 3]);
+            v4i fa[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = operand(R[st % 3][mt][kk]);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                v4i fb[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    fb[b] = *reinterpret_cast<const v4i*>(smem + fb_addr[kk] + st * B_STEP + b * 2048);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        if (st == 0 && kk == 0) {
+                            const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                            acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a][kk], fb[b], z, 0, 0, 0);
+                        } else {
+                            acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a][kk], fb[b], acc[a][b], 0, 0, 0);
+                        }
+                    }
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        epilogue(t);
+    }
+}
+
+template <int XS, int OUT, int KC>
+void launch_areg_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
+                      hipStream_t s) {
+    const long rows = mg.total_q * (mg.g.pool == 2 ? 4 : 1);
+    const int ntiles = (int)((rows + 63) / 64);              // 64-row wave tiles
+    const int ny = mg.g.cout / 64;
+    int gx = (((ntiles + 3) / 4 + 7) / 8) * 8;
+    const int cap = ((768 / ny + 7) / 8) * 8;               // three resident workgroups per CU
+    if (gx > cap) gx = cap;
+    const dim3 grid((unsigned)gx, (unsigned)ny), block(256);
+    const size_t lds = (size_t)9 * KC * 64 * 64;
+    static const bool lds_ok = [] {
+        (void)hipFuncSetAttribute((const void*)k_conv_mfma_areg<XS, OUT, 2, KC>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_conv_mfma_areg<XS, OUT, 1, KC>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        return true;
+    }();
+    (void)lds_ok;
+    if (mg.g.pool == 2)
+        hipLaunchKernelGGL((k_conv_mfma_areg<XS, OUT, 2, KC>), grid, block, lds, s, mg, e, (const uint8_t*)x, w, y, ntiles);
+    else
+        hipLaunchKernelGGL((k_conv_mfma_areg<XS, OUT, 1, KC>), grid, block, lds, s, mg, e, (const uint8_t*)x, w, y, ntiles);
+}
+
+template <int XS, int KC>
+int launch_areg(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
+                hipStream_t s) {
+    switch (e.out_store) {
+        case QNN_STORE_F32: launch_areg_pool<XS, QNN_STORE_F32, KC>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_BIN: launch_areg_pool<XS, QNN_STORE_BIN, KC>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_I4: launch_areg_pool<XS, QNN_STORE_I4, KC>(mg, e, x, w, y, s); return 0;
+        case QNN_STORE_I8: launch_areg_pool<XS, QNN_STORE_I8, KC>(mg, e, x, w, y, s); return 0;
+    }
+    return 1;
+}
+
 template <int XS, int OUT>
 void launch_wres_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
                       hipStream_t s) {
@@ -1370,6 +1675,18 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     const long rows_ = mg.total_q * (g.pool == 2 ? 4 : 1);
     const bool wres_fit = mg.steps <= 12 && rows_ < 2000000000L;
     const bool wres = wres_env == 0 ? false : wres_env == 1 ? wres_fit : (wres_fit && g.cout == 64 && !tile_env);
+    // 3x3, Cin <= 128: operands straight into registers (QNN_MFMA_AREG=0 disables, =1 also for Cout > 64)
+    static const int areg_env = getenv("QNN_MFMA_AREG") ? atoi(getenv("QNN_MFMA_AREG")) : -1;
+    const bool areg_fit = g.kh == 3 && g.kw == 3 && mg.kc <= 2 && rows_ < 2000000000L;
+    const bool areg = areg_env == 0 ? false : areg_env == 1 ? areg_fit : (areg_fit && g.cout == 64 && !tile_env && wres_env < 0);
+    if (areg) {
+        snprintf(name, name_len, "mfma_%s_areg64x64", x_store == QNN_STORE_I8 ? "i8" : "i4");
+        if (x_store == QNN_STORE_I8)
+            return mg.kc == 1 ? launch_areg<QNN_STORE_I8, 1>(mg, e2, x, w->d_mfma, y, s)
+                              : launch_areg<QNN_STORE_I8, 2>(mg, e2, x, w->d_mfma, y, s);
+        return mg.kc == 1 ? launch_areg<QNN_STORE_I4, 1>(mg, e2, x, w->d_mfma, y, s)
+                          : launch_areg<QNN_STORE_I4, 2>(mg, e2, x, w->d_mfma, y, s);
+    }
     if (wres) {
         snprintf(name, name_len, "mfma_%s_wres256x64", x_store == QNN_STORE_I8 ? "i8" : "i4");
         return x_store == QNN_STORE_I8 ? launch_wres<QNN_STORE_I8>(mg, e2, x, w->d_mfma, y, s)
