@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
                 const int py = (int)(qrow - (uint32_t)n * g.Hp);
                 const int iy0 = (py * POOL + (sub >> 1)) * g.stride - g.pt;
                 const int ix0 = (px * POOL + (sub & 1)) * g.stride - g.pl;
-                voff = ((n * g.H + iy0) * g.W + ix0) * mg.x_pix_bytes + lh * XCH;
+                voff = ((n * g.H + iy0) * g.W + ix0) * mg.x_pix_bytes + lh * (2 * XCH);
                 const int xlo = max(0, -ix0), xhi = min(3, g.W - ix0);
                 const int ylo = max(0, -iy0), yhi = min(3, g.H - iy0);
                 const uint32_t cm = xhi > xlo ? ((1u << xhi) - 1u) & ~((1u << xlo) - 1u) : 0u;
@@ -940,29 +940,29 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
             for (int tap = 0; tap < TAPS; ++tap) okm[tap][mt] = __ballot((m >> tap) & 1u);
         }
     };
-    using araw_t = typename std::conditional<XS == QNN_STORE_I8, uint4, uint2>::type;
-    araw_t R[3][2][2];                    // [set][32-row tile][k-block]
-    auto issue = [&](int st, araw_t (&r)[2][2]) {          // st = step within the tile (compile time)
+    // one operand register set = both k-blocks of both 32-row tiles.  Lane half lh owns the
+    // contiguous chunks 2*lh, 2*lh+1 of its pixel (k-block kk <-> chunk 2*lh + kk; the filter
+    // fragments below use the same order): int4 -> ONE 16-byte load per 32-row tile and step
+    struct aset_t { uint4 v[2][XS == QNN_STORE_I8 ? 2 : 1]; };
+    aset_t R[3];
+    auto issue = [&](int st, aset_t& r) {                  // st = step within the tile (compile time)
         const int tap = st / KC, kc = st % KC;
         const int xoff = ((tap / 3) * g.W + (tap % 3)) * mg.x_pix_bytes + kc * (4 * XCH);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm[tap][mt]);
             const int voff = ok ? a_voff[mt] + xoff : (int)0x80000000;   // out of range -> zeros
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if constexpr (XS == QNN_STORE_I8)
-                    r[mt][kk] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff + kk * 2 * XCH, 0, 0));
-                else
-                    r[mt][kk] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff + kk * 2 * XCH, 0, 0));
-            }
+            r.v[mt][0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
+            if constexpr (XS == QNN_STORE_I8)
+                r.v[mt][1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff + 16, 0, 0));
         }
     };
-    auto operand = [&](const araw_t& r) -> v4i {
-        if constexpr (XS == QNN_STORE_I8) return __builtin_bit_cast(v4i, r);
+    auto operand = [&](const aset_t& r, int mt, int kk) -> v4i {
+        if constexpr (XS == QNN_STORE_I8) return __builtin_bit_cast(v4i, r.v[mt][kk]);
         else {
-            const uint4 v = make_uint4((r.x << 4) & 0xF0F0F0F0u, r.x & 0xF0F0F0F0u,
-                                       (r.y << 4) & 0xF0F0F0F0u, r.y & 0xF0F0F0F0u);
+            const uint32_t lo = kk ? r.v[mt][0].z : r.v[mt][0].x, hi = kk ? r.v[mt][0].w : r.v[mt][0].y;
+            const uint4 v = make_uint4((lo << 4) & 0xF0F0F0F0u, lo & 0xF0F0F0F0u,
+                                       (hi << 4) & 0xF0F0F0F0u, hi & 0xF0F0F0F0u);
             return __builtin_bit_cast(v4i, v);
         }
     };
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
     // B fragment addresses: [kk]; the second 32-filter tile is +2048 bytes, a K-step +4096
     int fb_addr[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fb_addr[kk] = li * 64 + (((kk * 2 + lh) ^ ((li >> 2) & 3)) << 4);
+    for (int kk = 0; kk < 2; ++kk) fb_addr[kk] = li * 64 + (((lh * 2 + kk) ^ ((li >> 2) & 3)) << 4);
 
     v16i acc[2][2];
     auto bn = [&](int v, const FoldEpi& f) {
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = operand(R[st % 3][mt][kk]);
+                for (int kk = 0; kk < 2; ++kk) fa[mt][kk] = operand(R[st % 3], mt, kk);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 v4i fb[2];
