@@ -861,21 +861,18 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
 
-    // ---- the slice's filters -> LDS, all K-steps: rows of 64 bytes, chunks XOR-swizzled ----
+    // ---- the slice's filters: all K-steps, loads issued now, written to LDS further down so
+    // that the first tile's row decode and operand loads overlap their latency ----
+    const int srow = tid >> 2, sch = tid & 3;
+    uint4 wreg[S];
     {
-        const int srow = tid >> 2, sch = tid & 3;
         const int w_row_bytes = TAPS * g.cin;
         const int wv = (nbase + srow) * w_row_bytes + sch * 16;
-        uint4 wreg[S];
 #pragma unroll
         for (int st = 0; st < S; ++st)
             wreg[st] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                                                      wrsrc, wv, (st / KC) * g.cin + (st % KC) * 64, 0));
-#pragma unroll
-        for (int st = 0; st < S; ++st)
-            *reinterpret_cast<uint4*>(smem + st * B_STEP + srow * 64 + ((sch ^ ((srow >> 2) & 3)) << 4)) = wreg[st];
     }
-    __syncthreads();                                        // the only barrier
 
     // tiles of this wave: XCD x owns [x*per_xcd, (x+1)*per_xcd), its waves interleave
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -883,7 +880,6 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
     const int per_xcd = (ntiles + 7) >> 3;
     const int t_end = min((xcd + 1) * per_xcd, ntiles);
     int t = xcd * per_xcd + idx * 4 + wave;
-    if (t >= t_end) return;
 
     // ---- per-lane epilogue constants (power-of-two factors folded, see k_conv_first_lds) ----
     const bool binary = e.fn == QNN_FN_BINARY_TANH;
@@ -1045,14 +1041,36 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
         }
     };
 
+    // When a wave's tile stride covers whole images (and no tile is partial) the decoded rows
+    // are the same for all of its tiles up to the image base: advance the offsets by a constant
+    // instead of decoding again.
+    const int img_q = g.Hp * g.Wp;
+    const bool periodic = ((long)t_stride * TQ) % img_q == 0 && (long)ntiles * TQ == mg.total_q;
+    const int voff_step = (int)(((long)t_stride * TQ) / img_q) * g.H * g.W * mg.x_pix_bytes;
+    auto next_rows = [&](int tile) {
+        if (!periodic) row_setup(tile);
+        else if (tile < t_end) { a_voff[0] += voff_step; a_voff[1] += voff_step; }
+        else {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) { okm[tap][0] = 0; okm[tap][1] = 0; }
+        }
+    };
+
     // ---- main stream ----
-    row_setup(t);
+    row_setup(t);                                           // past this wave's range: all masks 0
     issue(0, R[0]);
     issue(1, R[1]);
+    {
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+            *reinterpret_cast<uint4*>(smem + st * B_STEP + srow * 64 + ((sch ^ ((srow >> 2) & 3)) << 4)) = wreg[st];
+    }
+    __syncthreads();                                        // the only barrier
+    if (t >= t_end) return;
     for (; t < t_end; t += t_stride) {
 #pragma unroll
         for (int st = 0; st < S; ++st) {
-            if (st == S - 2) row_setup(t + t_stride);       // the load stream enters the next tile
+            if (st == S - 2) next_rows(t + t_stride);       // the load stream enters the next tile
             issue((st + 2) % S, R[(st + 2) % 3]);
             v4i fa[2][2];
 #pragma unroll
