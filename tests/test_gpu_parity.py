@@ -205,6 +205,10 @@ LAYER_CASES = [
     ("i4_64_64_s2", (2, 14, 14, 64), 64, 3, 2, "quantized", 4, Q(4), "ps_i4_cw8_k3"),
     ("i8_128_64_1x1_s2", (2, 12, 12, 128), 64, 1, 2, "quantized", 8, Q(8), "generic"),
     ("i4_64_64_big", (37, 16, 16, 64), 64, 3, 1, "quantized", 4, Q(4), "ps_i4_cw8_k3"),
+    # two 64-channel groups per tap with one 64-filter slice (register-operand MFMA kernel, KC = 2)
+    ("i4_128_64", (2, 12, 12, 128), 64, 3, 1, "quantized", 4, Q(4), "ps_i4_cw16_k3"),
+    ("i8_128_64", (3, 9, 7, 128), 64, 3, 1, "quantized", 8, Q(8), ""),
+    ("i4_128_64_s2", (5, 13, 13, 128), 64, 3, 2, "quantized", 4, Q(4), "ps_i4_cw16_k3"),
 ]
 
 
