@@ -1447,6 +1447,23 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
         for (int j = 0; j < NJ; ++j)
             if (lane + 64 * j < TE) lds[lane + 64 * j] = stg[j];
     };
+    // When the wave stride is a whole number of images, a wave sees the same tile position
+    // (hence the same halo lanes) in every image: the per-lane byte offsets (or the out-of-range
+    // marker, which stays out of range under the additions) just advance by a constant, and no
+    // tile is decoded inside the loop.  Loads past the tensor end return zeros.
+    const int tiles_per_img = ((POOL == 2) ? g.Hp : g.H) * tiles_per_row;
+    const bool periodic = (nwaves % tiles_per_img) == 0;
+    const int img_step = nwaves / tiles_per_img;                    // images per wave stride
+    const int x_step = img_step * g.H * g.W * CIN * 4;
+    const long q_step = (long)img_step * ((POOL == 2) ? g.Hp * g.Wp : g.H * g.W);
+    int pvoff[NJ];
+    auto stage_load_next = [&]() {                                  // periodic mode: the next tile of this wave
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            stg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, pvoff[j], 0, 0));
+            pvoff[j] += x_step;
+        }
+    };
 
     // Order inside one iteration (tile i): MFMAs on the operands fetched during the previous
     // iteration -> hand tile i+1 from the staging registers to LDS, fetch its operands, start
@@ -1461,16 +1478,35 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
 #pragma unroll
         for (int s = 0; s < KS; ++s) av[s] = lds[op_idx[s]];
     };
-    stage_load(t);
-    stage_write(0);
-    fetch_operands();
-    stage_load(min(t + nwaves, tiles - 1));        // unconditional (clamped)
-    for (; t < tiles; t += nwaves) {
+    long q_run;
+    {
         int n, oy0, ox0;
         tile_origin(t, n, oy0, ox0);
-        // stored-pixel index of this tile's first window / pixel
-        const long q_base = (POOL == 2) ? ((long)n * g.Hp + (oy0 >> 1)) * g.Wp + (ox0 >> 1)
-                                        : ((long)n * g.H + oy0) * g.W + ox0;
+        q_run = (POOL == 2) ? ((long)n * g.Hp + (oy0 >> 1)) * g.Wp + (ox0 >> 1) : ((long)n * g.H + oy0) * g.W + ox0;
+        const int base4 = (((n * g.H + (oy0 - 1)) * g.W + (ox0 - 1)) * CIN) * 4;
+        const bool top = oy0 == 0, bot = oy0 + (TROWS - 2) == g.H;
+        const bool left = ox0 == 0, right = ox0 + (TCOLS - 2) == g.W;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned long long m = mX[j] | (top ? mT[j] : 0ull) | (bot ? mB[j] : 0ull) |
+                                         (left ? mL[j] : 0ull) | (right ? mR[j] : 0ull);
+            pvoff[j] = __builtin_amdgcn_inverse_ballot_w64(m) ? (int)0x80000000 : base4 + st_goff[j];
+        }
+    }
+    if (periodic) stage_load_next(); else stage_load(t);
+    stage_write(0);
+    fetch_operands();
+    if (periodic) stage_load_next(); else stage_load(min(t + nwaves, tiles - 1));   // unconditional (clamped)
+    for (; t < tiles; t += nwaves) {
+        long q_base;
+        if (periodic) { q_base = q_run; q_run += q_step; }
+        else {
+            int n, oy0, ox0;
+            tile_origin(t, n, oy0, ox0);
+            // stored-pixel index of this tile's first window / pixel
+            q_base = (POOL == 2) ? ((long)n * g.Hp + (oy0 >> 1)) * g.Wp + (ox0 >> 1)
+                                 : ((long)n * g.H + oy0) * g.W + ox0;
+        }
         uint32_t* ytile = reinterpret_cast<uint32_t*>(y) + q_base * e.ocw;   // packed outputs only
         if (kpad) av[KS - 1] = 0.0f;
 #pragma unroll
@@ -1489,7 +1525,7 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
                 __builtin_amdgcn_sched_barrier(0);
                 stage_write(0);
                 fetch_operands();
-                stage_load(min(t + 2 * nwaves, tiles - 1));
+                if (periodic) stage_load_next(); else stage_load(min(t + 2 * nwaves, tiles - 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
             auto bn = [&](float v, const FoldEpi& f) {
