@@ -93,9 +93,19 @@ def check(rc, what):
 IMPL_AUTO, IMPL_VALU, IMPL_MFMA = 0, 1, 2
 
 
+_conv_impl = IMPL_AUTO
+
+
 def set_conv_impl(impl):
     """0 auto, 1 VALU kernels only, 2 prefer int8 MFMA (bit-identical results)."""
+    global _conv_impl
     check(load().qnn_set_conv_impl(int(impl)), "qnn_set_conv_impl")
+    _conv_impl = int(impl)
+
+
+def conv_impl():
+    """The kernel-family preference last set through set_conv_impl()."""
+    return _conv_impl
 
 
 def last_kernel():

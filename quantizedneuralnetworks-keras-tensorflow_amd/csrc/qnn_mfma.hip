@@ -1689,6 +1689,12 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
         const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
         if (g.cout % pw != 0) return 1;
         snprintf(name, name_len, "mfma_f32_first_cin%d", g.cin);
+        // the LDS-staged kernel works on 64-filter slices (blockIdx.y): prefer it whenever its tiling applies
+        const bool lds_shape = g.stride == 1 && g.pt == 1 && g.pl == 1 &&
+                               ((g.pool == 2 && (g.Wp % 8) == 0 && (g.H % 2) == 0 && (g.W % 2) == 0) ||
+                                (g.pool == 1 && (g.W % 32) == 0));
+        if (lds_shape && !getenv("QNN_FIRST_GATHER"))
+            return g.cin == 3 ? launch_first<3, 2>(g, e, x, w->d_wq, y, s) : launch_first<1, 2>(g, e, x, w->d_wq, y, s);
         if (g.cout == 64)
             return g.cin == 3 ? launch_first<3, 2>(g, e, x, w->d_wq, y, s) : launch_first<1, 2>(g, e, x, w->d_wq, y, s);
         if (g.cout == 128)

@@ -75,6 +75,21 @@ def _join_store(act_bits, wstore):
     return max(a, w, _abi.STORE_I4)
 
 
+def _matrix_pipe_1bit(op):
+    """True if a 1-bit x 1-bit conv should take the int8 matrix pipe instead of XNOR+popcount.
+
+    On MI355X the int8 MFMA kernel with register-resident operands (k_conv_mfma_areg: 3x3,
+    Cin <= 128, one 64-filter slice) runs the CIFAR B0 layer in 34 us against 76 us for the
+    XNOR kernel at 81 % of the popcount ceiling (profiles/r01), with bit-identical results:
+    the +-1 codes are then stored as int4 between the layers (8 KB instead of 2 KB per image,
+    far below any bandwidth limit).  VALU-only mode keeps the bit-packed path.
+    """
+    if _abi.conv_impl() == _abi.IMPL_VALU or op is None or op["op"] != "conv" or op["kind"] != "binary":
+        return False
+    kh, kw, cin, cout = op["kernel"].shape
+    return kh == 3 and kw == 3 and cin in (64, 128) and cout == 64
+
+
 def _prepack(op, store, device, stride=1, same_pad=True):
     kernel = torch.as_tensor(np.ascontiguousarray(op["kernel"], dtype=F32)).to(device)
     bias = op.get("bias")
@@ -120,6 +135,8 @@ class FusedModel:
                 out_store = _join_store(bits, _wstore(nxt)) if nxt is not None else _abi.STORE_F32
                 if out_store is None:
                     raise _abi.QnnError("FusedModel: float layer after a low-bit activation")
+                if out_store == _abi.STORE_BIN and _matrix_pipe_1bit(nxt):
+                    out_store = _abi.STORE_I4
             self.steps.append(dict(kind=g["kind"], w=w, x_store=x_store, x_bits=x_bits, inv=inv,
                                    shift=shift, fn=fn, act_bits=bits if fn == _abi.FN_QUANTIZED_TANH else 0,
                                    pool=g["pool"], out_store=out_store, softmax=g.get("softmax", False)))

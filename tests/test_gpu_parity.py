@@ -451,6 +451,29 @@ def test_vgg_configs_end_to_end(idx, impl):
     assert frac <= 0.2, frac
 
 
+def test_one_bit_layers_on_the_matrix_pipe():
+    """full-bnn VGG: the fused engine stores +-1 codes as int4 in front of 3x3 64->64 layers so
+    that they run on the int8 MFMA kernel; VALU-only mode keeps the bit-packed XNOR path; both
+    are bit-exact against the oracle."""
+    cf = nets.baseline_config(1)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 1)
+    x = nets.synthetic_images(cf, 5, nets.SEED_BASE + 1)
+    want = O.run_spec(spec, x, float_conv="device")
+    try:
+        _abi.set_conv_impl(_abi.IMPL_AUTO)
+        fused = engine.FusedModel(spec)
+        stores = [st["x_store"] for st in fused.steps]
+        assert _abi.STORE_I4 in stores and stores[0] == _abi.STORE_F32, stores
+        got = host(fused(dev(x)))
+        np.testing.assert_array_equal(got, want)
+        _abi.set_conv_impl(_abi.IMPL_VALU)
+        fused_v = engine.FusedModel(spec)
+        assert _abi.STORE_I4 not in [st["x_store"] for st in fused_v.steps]
+        np.testing.assert_array_equal(host(fused_v(dev(x))), want)
+    finally:
+        _abi.set_conv_impl(_abi.IMPL_AUTO)
+
+
 def test_vgg_large_8bit_small_batch(impl):
     cf = nets.baseline_config(3)
     spec = nets.build_spec(cf, nets.SEED_BASE + 3)
