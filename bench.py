@@ -77,8 +77,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("QNN_DIST_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on a 1-GPU box
-    if world > 1:
+    # QNN_BENCH_FORCE_DIST=1: run the N>1 code path (process group, logits all-gather) with a
+    # single rank -- the only way to exercise the RCCL calls on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("QNN_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
@@ -98,7 +102,7 @@ def main():
 
     def step():
         y = model(x)
-        if world == 1:
+        if not use_dist:
             return y
         if backend == "gloo":                      # rehearsal path: gloo gathers host tensors
             return shard.gather_logits(y.cpu())
@@ -154,44 +158,81 @@ def main():
                                bytes=30307912 * N, macs=6855277184 * N))   # M1 bytes/img, SURVEY.md 8d
     dom = max(range(len(per_kernel)), key=lambda i: per_kernel[i]["ms"])
 
-    # ---- optional hipGraph of the whole forward (launch-bound inner loop) ----
+    # ---- hipGraph of the model forward (launch-bound inner loop); the logits all-gather stays
+    # outside the graph and runs on RCCL's own stream, overlapped with the next batch ----
     graph = None
-    if args.graph and world == 1:
+    y_static = None
+    if args.graph:
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(2):
-                    step()
+                    model(x)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                y_static = step()
+                y_static = model(x)
             graph = g
         except Exception as exc:  # pragma: no cover
             print("hipGraph capture failed (%s); running eagerly" % exc, file=sys.stderr)
             graph = None
 
+    # logits exchange (N > 1): the (B, classes) float32 block of this rank is copied to one of two
+    # staging buffers and all-gathered asynchronously; the next forward does not wait for it, the
+    # buffer is only reused after its gather has been waited for (stream-level wait, no host block)
+    pipelined = use_dist and backend != "gloo" and graph is not None
+    stage, gathered, works = [], [], [None, None]
+    if pipelined:
+        for _ in range(2):
+            stage.append(torch.empty_like(y_static))
+            gathered.append(torch.empty((world * y_static.shape[0],) + tuple(y_static.shape[1:]),
+                                        dtype=y_static.dtype, device=y_static.device))
+    counter = [0]
+
     def run_step():
-        if graph is not None:
-            graph.replay()
-        else:
+        if graph is None:
             step()
+            return
+        graph.replay()
+        if not use_dist:
+            return
+        if not pipelined:
+            shard.gather_logits(y_static.cpu() if backend == "gloo" else y_static)
+            return
+        k = counter[0] & 1
+        counter[0] += 1
+        if works[k] is not None:
+            works[k].wait()
+        stage[k].copy_(y_static)
+        works[k] = dist.all_gather_into_tensor(gathered[k], stage[k], async_op=True)
+
+    def drain():
+        for k in range(2):
+            if works[k] is not None:
+                works[k].wait()
+                works[k] = None
 
     for _ in range(args.warmup):
         run_step()
+    drain()
     # dominant-kernel events inside the timed region only make sense eagerly; with a
     # graph the per-kernel figure above (same launches, same stream) is reported
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step()
-    torch.cuda.synchronize()
-    if world > 1:
+    drain()                                        # every gather of the timed steps has completed ...
+    torch.cuda.synchronize()                       # ... before the clock stops
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if pipelined and rank == 0:
+        # the gathered block must hold this rank's logits at its own offset
+        torch.testing.assert_close(gathered[(counter[0] - 1) & 1][rank * y_static.shape[0]:(rank + 1) * y_static.shape[0]],
+                                   y_static, rtol=0, atol=0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,7 +298,7 @@ def main():
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"error": str(exc)}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
