@@ -418,6 +418,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
     }
 }
 
+// 16x16x64 variant, defined below (it uses the folded-epilogue helpers)
+template <int XS, int WM, int WN, int OUT, int POOL>
+__global__ void k_conv_mfma16(MfmaGeom mg, EpiArgs e, const uint8_t* __restrict__ x,
+                              const uint8_t* __restrict__ wq8, void* __restrict__ y);
+
 template <int XS, int WM, int WN, int OUT>
 void launch_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
                  hipStream_t s) {
@@ -426,6 +431,19 @@ void launch_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     const dim3 grid((unsigned)((rows + BM - 1) / BM), (unsigned)(mg.g.cout / BN));
     const dim3 block(64 * WM * WN);
     const size_t lds = 2 * (BM + BN) * 64;
+    // the large tiles (16 / 8 waves per workgroup, four waves per SIMD) use the 16x16x64 shape
+    if constexpr (OUT != QNN_STORE_BIN && WM == 4 && WN >= 2) {
+        static const int shape = getenv("QNN_MFMA_SHAPE") ? atoi(getenv("QNN_MFMA_SHAPE")) : 16;
+        if (shape == 16) {
+            if (mg.g.pool == 2)
+                hipLaunchKernelGGL((k_conv_mfma16<XS, WM, WN, OUT, 2>), grid, block, lds, s, mg, e,
+                                   (const uint8_t*)x, w, y);
+            else
+                hipLaunchKernelGGL((k_conv_mfma16<XS, WM, WN, OUT, 1>), grid, block, lds, s, mg, e,
+                                   (const uint8_t*)x, w, y);
+            return;
+        }
+    }
     if (mg.g.pool == 2)
         hipLaunchKernelGGL((k_conv_mfma<XS, WM, WN, OUT, 2>), grid, block, lds, s, mg, e,
                            (const uint8_t*)x, w, y);
@@ -481,6 +499,308 @@ __device__ __forceinline__ uint32_t pack_scaled(const float* tm, float m, bool b
         word |= (uint32_t)S << (16 * h);
     }
     return word;
+}
+
+// ---------------------------------------------------------------------------------
+// Same implicit GEMM on v_mfma_i32_16x16x64_i8.  On random operands the chip holds a lower
+// clock under 32x32x32 at four waves per SIMD than under 16x16x64 (tools/ubench_shape.hip:
+// 1 474 vs 1 693 T MAC/s for a bare register loop), and the large tiles of the 8-bit VGG
+// layers run exactly at that occupancy.  Same staging, same LDS traffic (4 + 4 fragment reads
+// of 16 bytes per step and wave), 16 MFMAs of 16 cycles instead of 8 of 32; the 64-byte rows
+// use a chunk permutation that is conflict-free for this fragment shape.  The 2x2 pool window
+// is still the four accumulator registers of one lane.  Outputs: float32, int4, int8.
+template <int XS, int WM, int WN, int OUT, int POOL>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2 : 3)) void k_conv_mfma16(MfmaGeom mg, EpiArgs e,
+                                                           const uint8_t* __restrict__ x,
+                                                           const uint8_t* __restrict__ wq8,
+                                                           void* __restrict__ y) {
+    constexpr int T = 64 * WM * WN;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int RPP = T / 4;               // rows staged per pass
+    constexpr int NA = BM / RPP, NB = BN / RPP;
+    constexpr int XCH = (XS == QNN_STORE_I8) ? 16 : 8;     // stored bytes per 16-channel chunk
+    static_assert(NA >= 1 && NB >= 1, "tile too small for the workgroup");
+    const ConvGeom& g = mg.g;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // chunk swizzle of a 64-byte row: conflict-free for the 16x16x64 fragment reads (16 rows of one
+    // chunk per 16 lanes; ds_read_b128 lane groups {0-3,12-15,20-27} ...) and for the staging writes
+    auto swz = [](int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };      // {0,2,3,1}[(row>>2)&3]
+    constexpr int A_BUF = BM * 64, B_BUF = BN * 64;
+    constexpr int B_BASE = 2 * A_BUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share
+    // an L2), so give each XCD a contiguous range of M-tiles: neighbouring tiles share their
+    // halo rows (and all of them the weights) in that XCD's L2.  Bijective for any grid size.
+    long tile;
+    {
+        const unsigned nb_ = gridDim.x, b_ = blockIdx.x;
+        const unsigned q_ = nb_ / 8, r_ = nb_ % 8, xcd = b_ % 8, idx = b_ / 8;
+        tile = (mg.ablate & 4) ? (long)b_
+                               : (long)((xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx);
+    }
+    const int nbase = blockIdx.y * BN;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(x), 0, (int)mg.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
+
+    // ---- per-thread staging rows: byte offset of the receptive field's top-left
+    // pixel (+ this thread's chunk) and a 9-bit "tap is inside the image" mask --------
+    const int srow = tid >> 2, sch = tid & 3;
+    int a_voff[NA];
+    uint32_t a_mask[NA];
+    int a_lds[NA], b_lds[NB], b_voff[NB];
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+        const int R = srow + p * RPP;
+        long q;
+        int sub = 0;
+        if constexpr (POOL == 2) { q = tile * (BM / 4) + (R >> 2); sub = R & 3; }
+        else q = tile * BM + R;
+        a_mask[p] = 0;
+        a_voff[p] = 0;
+        if (q < mg.total_q) {
+            const uint32_t qrow = qnn_div((uint32_t)q, g.fd_wp);
+            const int px = (int)((uint32_t)q - qrow * g.Wp);
+            const int n = (int)qnn_div(qrow, g.fd_hp);
+            const int py = (int)(qrow - (uint32_t)n * g.Hp);
+            const int iy0 = (py * POOL + (sub >> 1)) * g.stride - g.pt;
+            const int ix0 = (px * POOL + (sub & 1)) * g.stride - g.pl;
+            a_voff[p] = ((n * g.H + iy0) * g.W + ix0) * mg.x_pix_bytes + sch * XCH;
+            for (int dy = 0; dy < g.kh; ++dy)
+                for (int dx = 0; dx < g.kw; ++dx)
+                    if ((unsigned)(iy0 + dy) < (unsigned)g.H && (unsigned)(ix0 + dx) < (unsigned)g.W)
+                        a_mask[p] |= 1u << (dy * g.kw + dx);
+        }
+        a_lds[p] = R * 64 + ((sch ^ swz(R)) << 4);
+    }
+    const int w_row_bytes = g.kh * g.kw * g.cin;   // int8 bytes per cout
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        const int R = srow + p * RPP;
+        b_voff[p] = (nbase + R) * w_row_bytes + sch * 16;
+        b_lds[p] = B_BASE + R * 64 + ((sch ^ swz(R)) << 4);
+    }
+
+    // ---- fragment read addresses (constant per lane): 16x16x64 operands = row (lane & 15),
+    // 16-byte chunk (lane >> 4) of a 16-row tile; tile t of the wave's 64 rows is +1024 bytes ----
+    const int cq = lane & 15, rg = lane >> 4;
+    int fa_addr, fb_addr;
+    {
+        const int ra_ = wm * 64 + cq;
+        fa_addr = ra_ * 64 + ((rg ^ swz(ra_)) << 4);
+        const int rb_ = wn * 64 + cq;
+        fb_addr = B_BASE + rb_ * 64 + ((rg ^ swz(rb_)) << 4);
+    }
+
+    // uniform K-step state, advanced incrementally (no divisions in the loop)
+    int s_tap = 0, s_kc = 0, s_dy = 0, s_dx = 0;
+    // two staging register sets (2-deep prefetch); int4 activations stay packed (8 B per
+    // 16-channel chunk) until they are written to LDS
+    using araw_t = typename std::conditional<XS == QNN_STORE_I8, uint4, uint2>::type;
+    araw_t raA[NA], raB[NA];
+    uint4 rbA[NB], rbB[NB];
+    auto stage_load = [&](araw_t (&ra)[NA], uint4 (&rb)[NB]) {
+        const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
+        const int woff = (s_tap < g.kh * g.kw && !(mg.ablate & 2)) ? s_tap * g.cin + s_kc * 64
+                                                                    : (int)0x40000000;   // past the end -> zeros
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const bool ok = ((a_mask[p] >> s_tap) & 1u) && !(mg.ablate & 1);
+            const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;   // out of range -> zeros
+            if constexpr (XS == QNN_STORE_I8)
+                ra[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
+            else
+                ra[p] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0));
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+            rb[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_voff[p], woff, 0));
+        // advance (tap, kc)
+        if (++s_kc == mg.kc) {
+            s_kc = 0; ++s_tap;
+            if (++s_dx == g.kw) { s_dx = 0; ++s_dy; }
+        }
+    };
+
+    v4i acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4i){0, 0, 0, 0};
+
+    auto stage_write = [&](const araw_t (&ra)[NA], const uint4 (&rb)[NB], int bufoff_a, int bufoff_b) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            uint4 v;
+            if constexpr (XS == QNN_STORE_I8) v = ra[p];
+            else v = make_uint4((ra[p].x << 4) & 0xF0F0F0F0u, ra[p].x & 0xF0F0F0F0u,
+                                (ra[p].y << 4) & 0xF0F0F0F0u, ra[p].y & 0xF0F0F0F0u);
+            *reinterpret_cast<uint4*>(smem + a_lds[p] + bufoff_a) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) *reinterpret_cast<uint4*>(smem + b_lds[p] + bufoff_b) = rb[p];
+    };
+    auto compute = [&](int bufoff_a, int bufoff_b) {
+        v4i fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // swz() only depends on bits 2-3 of the row, which adding 16*t does not change
+            fa[t] = *reinterpret_cast<const v4i*>(smem + fa_addr + bufoff_a + t * 1024);
+            fb[t] = *reinterpret_cast<const v4i*>(smem + fb_addr + bufoff_b + t * 1024);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- main loop: one barrier per K-step; the loads of step k+2 are issued before the
+    // MFMAs of step k and only waited for (counted vmcnt) after the MFMAs of step k+1 ----
+    // Loads are issued UNCONDITIONALLY (a step past the end has tap >= kh*kw, whose mask
+    // bit is 0 -> out-of-range offset -> the buffer load returns zeros without touching
+    // memory): conditional loads make the compiler fall back to vmcnt(0).
+    const int S = mg.steps;
+    stage_load(raA, rbA);                          // step 0
+    stage_load(raB, rbB);                          // step 1
+    stage_write(raA, rbA, 0, 0);
+    __syncthreads();
+    int ks = 0;
+    for (; ks + 1 < S; ks += 2) {
+        stage_load(raA, rbA);                      // step ks+2 -> set A
+        compute(0, 0);                             // step ks   (buffer 0)
+        stage_write(raB, rbB, A_BUF, B_BUF);       // step ks+1 -> buffer 1
+        __syncthreads();
+        stage_load(raB, rbB);                      // step ks+3 -> set B
+        compute(A_BUF, B_BUF);                     // step ks+1 (buffer 1)
+        stage_write(raA, rbA, 0, 0);               // step ks+2 -> buffer 0
+        __syncthreads();
+    }
+    if (ks < S) compute(0, 0);                     // odd step count: last step sits in buffer 0
+
+    // ---- epilogue: C/D layout of 16x16: lane holds column (lane & 15) and rows 4*(lane >> 4) + r
+    // of each tile -> the four registers of a tile are one 2x2 pool window of one channel ----
+    static_assert(OUT != QNN_STORE_BIN, "1-bit outputs take the 32x32x32 kernel");
+    const bool binary = e.fn == QNN_FN_BINARY_TANH;
+    constexpr bool PACKED = OUT == QNN_STORE_I4 || OUT == QNN_STORE_I8;
+    const float mfold = (PACKED && !binary) ? e.act_m : 1.0f;
+    LaneEpi ke;                               // selector constants of the transposes (lane & 7 / lane & 3)
+    lane_epi_init<OUT>(ke, e, nbase + wn * 64 + cq, cq);
+    FoldEpi fe[4];
+    bool neg[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        LaneEpi kb;
+        lane_epi_init<OUT>(kb, e, nbase + wn * 64 + b * 16 + cq, cq);
+        neg[b] = kb.neg;
+        fe[b].nb = __fdiv_rn(kb.bias, e.scale);
+        fe[b].ninv = __fmul_rn(__fmul_rn(kb.inv, e.scale), mfold);
+        fe[b].nshift = __fmul_rn(kb.shift, mfold);
+    }
+    auto bn = [&](int v, const FoldEpi& f) {
+        return __fadd_rn(__fmul_rn(__fadd_rn((float)v, f.nb), f.ninv), f.nshift);
+    };
+    auto finish = [&](float t) {              // float32 outputs: the activation on the unscaled value
+        if (e.fn == QNN_FN_BINARY_TANH) return qnn_binary_tanh(t);
+        if (e.fn == QNN_FN_QUANTIZED_TANH) return qnn_quantized_tanh(t, e.act_m);
+        return t;
+    };
+    const int cb = nbase + wn * 64 + cq;       // channel of tile column b: cb + 16*b
+    if constexpr (POOL == 2) {
+        // window (a, rg): stored pixel q = tile*(BM/4) + wm*16 + a*4 + rg
+        float tv[4][4];                         // [b][a]
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const v4i v = acc[a][b];
+                const int mx = max(max(v[0], v[1]), max(v[2], v[3]));
+                const int mn = min(min(v[0], v[1]), min(v[2], v[3]));
+                tv[b][a] = bn(neg[b] ? mn : mx, fe[b]);
+            }
+        const long q0 = tile * (BM / 4) + wm * 16 + rg;
+        if constexpr (OUT == QNN_STORE_F32) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const long q = q0 + a * 4;
+                    if (q < mg.total_q) ((float*)y)[q * g.cout + cb + 16 * b] = finish(tv[b][a]);
+                }
+        } else if constexpr (OUT == QNN_STORE_I4) {
+            // one nibble transpose per pair of tile columns: value j = (b & 1) * 4 + a
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp) {
+                float t8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t8[j] = tv[2 * bp + (j >> 2)][j & 3];
+                const uint32_t P = pack_scaled<4, 8>(t8, e.act_m, binary);
+                const uint32_t Wd = transpose_nib8(P, ke) ^ 0x88888888u;
+                const int j = cq & 7;            // after the transpose this lane holds value j of its octet
+                const long q = q0 + (j & 3) * 4;
+                const int c = cb + 16 * (2 * bp + (j >> 2));
+                if (q < mg.total_q) ((uint32_t*)y)[q * e.ocw + (c >> 3)] = Wd;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t P = pack_scaled<8, 4>(tv[b], e.act_m, binary);
+                const uint32_t Wd = transpose_byte4(P, ke) ^ 0x80808080u;
+                const long q = q0 + (cq & 3) * 4;
+                if (q < mg.total_q) ((uint32_t*)y)[q * e.ocw + ((cb + 16 * b) >> 2)] = Wd;
+            }
+        }
+    } else {
+        // row (a, rg, r): stored pixel q = tile*BM + wm*64 + a*16 + rg*4 + r
+        const long q0 = tile * BM + wm * 64 + rg * 4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float tv[4][4];                     // [b][r]
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tv[b][r] = bn(acc[a][b][r], fe[b]);
+            if constexpr (OUT == QNN_STORE_F32) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long q = q0 + a * 16 + r;
+                        if (q < mg.total_q) ((float*)y)[q * g.cout + cb + 16 * b] = finish(tv[b][r]);
+                    }
+            } else if constexpr (OUT == QNN_STORE_I4) {
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp) {
+                    float t8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t8[j] = tv[2 * bp + (j >> 2)][j & 3];
+                    const uint32_t P = pack_scaled<4, 8>(t8, e.act_m, binary);
+                    const uint32_t Wd = transpose_nib8(P, ke) ^ 0x88888888u;
+                    const int j = cq & 7;
+                    const long q = q0 + a * 16 + (j & 3);
+                    const int c = cb + 16 * (2 * bp + (j >> 2));
+                    if (q < mg.total_q) ((uint32_t*)y)[q * e.ocw + (c >> 3)] = Wd;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t P = pack_scaled<8, 4>(tv[b], e.act_m, binary);
+                    const uint32_t Wd = transpose_byte4(P, ke) ^ 0x80808080u;
+                    const long q = q0 + a * 16 + (cq & 3);
+                    if (q < mg.total_q) ((uint32_t*)y)[q * e.ocw + ((cb + 16 * b) >> 2)] = Wd;
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
