@@ -1,3 +1,7 @@
+#!/bin/bash
+# Run on the GPU box: rocprofv3 kernel-trace durations of bench.py for the in-tree library and for
+# any number of alternative builds csrc/libqnn_v_<tag>.so (built with -D switches for A/B timing).
+# Usage: tools/trace_kernels.sh [tag ...]
 D=quantizedneuralnetworks-keras-tensorflow_amd/csrc
 ROOT=$(pwd)
 cp $D/libqnn_hip.so /tmp/orig.so
