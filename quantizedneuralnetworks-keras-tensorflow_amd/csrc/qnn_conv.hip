@@ -929,7 +929,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
             snprintf(name, sizeof(name), "dense_%s", x_store == QNN_STORE_BIN ? "bin" : x_store == QNN_STORE_I4 ? "i4" : "i8");
         }
     }
-    if (!launched && pref != 1 && !dense && !e.res)
+    if (!launched && pref != 1 && !dense)          // residual epilogues: only where the MFMA kernel has one
         launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
     if (!launched && x_store == QNN_STORE_BIN && !dense && !e.res)
         launched = try_launch_xnor_pk(g, e, x, w, y, s, name, sizeof(name)) == 0;

@@ -1203,7 +1203,11 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
 
     // ---- per-lane epilogue constants (power-of-two factors folded, see k_conv_first_lds) ----
     const bool binary = e.fn == QNN_FN_BINARY_TANH;
-    const float mfold = (PACKED && !binary) ? e.act_m : 1.0f;
+    // residual merge (models/resnet.py:127-128, un-pooled layers only): needs the unscaled
+    // post-BN value, so the code scale is applied after the merge instead of being folded
+    const bool has_res = POOL == 1 && e.res != nullptr;
+    const float mfold = (PACKED && !binary && !has_res) ? e.act_m : 1.0f;
+    const float mlate = (PACKED && !binary && has_res) ? e.act_m : 1.0f;
     LaneEpi ke[2];
     FoldEpi fe[2];
 #pragma unroll
@@ -1335,6 +1339,13 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
                     float tv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) tv[r] = bn(acc[a][b][r], fe[b]);
+                    if (has_res) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const long q = row0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (q < mg.total_q) tv[r] = __fmul_rn(qnn_epi_residual(tv[r], q, c, e), mlate);
+                        }
+                    }
                     if constexpr (OUT == QNN_STORE_I4) {
 #pragma unroll
                         for (int gq = 0; gq < 2; ++gq) {
@@ -2004,6 +2015,7 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                         const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len) {
     if (x_store == QNN_STORE_F32) {
         // float-input first layer on the f32 matrix pipe
+        if (e.res) return 1;
         if (g.kh != 3 || g.kw != 3 || (g.cin != 1 && g.cin != 3)) return 1;
         if (g.cout != 64 && g.cout != 128 && g.cout != 256) return 1;
         const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
@@ -2059,6 +2071,7 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     static const int areg_env = getenv("QNN_MFMA_AREG") ? atoi(getenv("QNN_MFMA_AREG")) : -1;
     const bool areg_fit = g.kh == 3 && g.kw == 3 && mg.kc <= 2 && rows_ < 2000000000L;
     const bool areg = areg_env == 0 ? false : areg_env == 1 ? areg_fit : (areg_fit && g.cout == 64 && !tile_env && wres_env < 0);
+    if (e.res && !(areg && g.pool == 1)) return 1;          // the other MFMA kernels have no residual epilogue
     if (areg) {
         snprintf(name, name_len, "mfma_%s_areg64x64", x_store == QNN_STORE_I8 ? "i8" : "i4");
         if (x_store == QNN_STORE_I8)
