@@ -158,7 +158,8 @@ __device__ __forceinline__ void store_values(const float (&t)[NV], const LaneEpi
             if (e.fn == QNN_FN_BINARY_TANH) r = qnn_binary_tanh(r);
             else if (e.fn == QNN_FN_QUANTIZED_TANH) r = qnn_quantized_tanh(r, e.act_m);
             const long q = qof(j);
-            if (q < total_q) ((float*)y)[q * cout + cof(j)] = r;
+            // float32 surfaces are written once and are far larger than L2: non-temporal
+            if (q < total_q) __builtin_nontemporal_store(r, &((float*)y)[q * cout + cof(j)]);
         }
     } else if constexpr (OUT == QNN_STORE_BIN) {
         // one ballot per value: bits of lanes 0-31 / 32-63 are the 32 channels of the
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const long q = q0 + a * 4;
-                    if (q < mg.total_q) ((float*)y)[q * g.cout + cb + 16 * b] = finish(tv[b][a]);
+                    if (q < mg.total_q) ((float*)y)[q * g.cout + cb + 16 * b] = finish(tv[b][a]);   // 64-byte segments: no nt hint
                 }
         } else if constexpr (OUT == QNN_STORE_I4) {
             // one nibble transpose per pair of tile columns: value j = (b & 1) * 4 + a
