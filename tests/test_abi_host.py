@@ -166,3 +166,27 @@ def test_fused_chain_grouping_and_residual_planning():
     bcf = nets.Config(network_type="full-bnn", architecture="RESNET", nres=1, dim=32)
     mb = engine.ResidualFusedModel(nets.build_spec(bcf, 2), device="cpu")
     assert _abi.STORE_BIN in {mb._act_out_store(n, 1) for n, i in mb.prod.items() if mb.spec[i]["op"] == "act"}
+
+
+def test_one_bit_layers_choose_the_matrix_pipe_by_shape_and_impl():
+    """engine._matrix_pipe_1bit: 3x3, Cin in {64,128}, Cout == 64 binary convs go to the int8
+    MFMA kernel (int4-stored +-1 codes) unless the VALU-only family is selected."""
+    from qnn_amd import _abi, engine
+    k = lambda kh, cin, cout: np.zeros((kh, kh, cin, cout), np.float32)
+    conv = lambda kind, kern: {"op": "conv", "kind": kind, "kernel": kern}
+    saved = _abi._conv_impl
+    try:
+        _abi._conv_impl = _abi.IMPL_AUTO
+        assert engine._matrix_pipe_1bit(conv("binary", k(3, 64, 64)))
+        assert engine._matrix_pipe_1bit(conv("binary", k(3, 128, 64)))
+        assert not engine._matrix_pipe_1bit(conv("binary", k(3, 64, 128)))      # more than one filter slice
+        assert not engine._matrix_pipe_1bit(conv("binary", k(1, 64, 64)))       # 1x1
+        assert not engine._matrix_pipe_1bit(conv("binary", k(3, 32, 64)))       # Cin not a multiple of 64
+        assert not engine._matrix_pipe_1bit(conv("quantized", k(3, 64, 64)))    # not a 1-bit layer
+        assert not engine._matrix_pipe_1bit({"op": "dense", "kind": "binary", "kernel": np.zeros((64, 10), np.float32)})
+        assert not engine._matrix_pipe_1bit(None)
+        _abi._conv_impl = _abi.IMPL_VALU
+        assert not engine._matrix_pipe_1bit(conv("binary", k(3, 64, 64)))
+        assert _abi.conv_impl() == _abi.IMPL_VALU
+    finally:
+        _abi._conv_impl = saved
