@@ -138,12 +138,10 @@ __global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ x,
     const size_t stride = (size_t)gridDim.x * kBlock;
     const bool vec = (channels % PW) == 0;   // full words, 16-B aligned channel groups
     for (size_t wi = (size_t)blockIdx.x * kBlock + threadIdx.x; wi < words; wi += stride) {
-        const size_t p = wi / cw;
-        const int w = (int)(wi - p * cw);
-        const float* src = x + p * (size_t)channels + (size_t)w * PW;
         uint32_t out = 0;
         if (vec) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
+            // channels == cw * PW: word wi packs the PW floats at x + wi * PW (no pixel decode)
+            const float4* s4 = reinterpret_cast<const float4*>(x + wi * PW);
 #pragma unroll
             for (int j = 0; j < PW / 4; ++j) {
                 float4 v = s4[j];
@@ -153,6 +151,9 @@ __global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ x,
                 out |= (encode_one<STORE>(v.w, fn, m) & MASK) << ((4 * j + 3) * BITS);
             }
         } else {
+            const size_t p = wi / cw;
+            const int w = (int)(wi - p * cw);
+            const float* src = x + p * (size_t)channels + (size_t)w * PW;
             const int left = channels - w * PW;
             for (int j = 0; j < PW && j < left; ++j)
                 out |= (encode_one<STORE>(src[j], fn, m) & MASK) << (j * BITS);
