@@ -241,6 +241,66 @@ __global__ __launch_bounds__(kBlock) void k_conv_generic(ConvGeom g, EpiArgs e, 
 }
 
 // ---------------------------------------------------------------------------
+// dense layer on float32 features (the classifier behind a global average pool,
+// models/resnet.py:138-142): the same ascending-k fmaf chain as conv_point
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dense_f32in(EpiArgs e, int N, int cin, int cout,
+                                                    const float* __restrict__ x,
+                                                    const float* __restrict__ wq,
+                                                    float* __restrict__ y) {
+    // One wave per (row, output).  The chain is sequential by definition (ascending k, one
+    // rounding per fmaf), so the wave only parallelises the operand traffic: 64 lanes fetch a
+    // 256-element chunk of both vectors with coalesced 16-byte loads into LDS, then every lane
+    // runs the same chain on LDS broadcast reads (a thread-per-output loop pays one global
+    // round trip per four elements: 130 us for the 3136 -> 10 ResNet classifier, here ~10 us).
+    constexpr int CH = 256;
+    __shared__ __attribute__((aligned(16))) float xs[2][CH], ws[2][CH];
+    const int t = blockIdx.x;
+    const int n = t / cout, c = t - n * cout;
+    const int lane = threadIdx.x;
+    const float* a = x + (size_t)n * cin;
+    const float* w = wq + (size_t)c * cin;
+    const bool vec = (cin & 3) == 0;
+    auto fetch = [&](int k0, int buf) {
+        const int k = k0 + 4 * lane;
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
+        if (vec && k + 3 < cin) {
+            av = *reinterpret_cast<const float4*>(a + k);
+            wv = *reinterpret_cast<const float4*>(w + k);
+        } else {
+            if (k < cin) { av.x = a[k]; wv.x = w[k]; }
+            if (k + 1 < cin) { av.y = a[k + 1]; wv.y = w[k + 1]; }
+            if (k + 2 < cin) { av.z = a[k + 2]; wv.z = w[k + 2]; }
+            if (k + 3 < cin) { av.w = a[k + 3]; wv.w = w[k + 3]; }
+        }
+        *reinterpret_cast<float4*>(&xs[buf][4 * lane]) = av;
+        *reinterpret_cast<float4*>(&ws[buf][4 * lane]) = wv;
+    };
+    float acc = 0.0f;
+    fetch(0, 0);
+    int buf = 0;
+    for (int k0 = 0; k0 < cin; k0 += CH, buf ^= 1) {
+        __syncthreads();                               // chunk k0 is in LDS (single wave: cheap)
+        if (k0 + CH < cin) fetch(k0 + CH, buf ^ 1);    // next chunk in flight under the chain
+        const int cnt = min(CH, cin - k0);
+        int k = 0;
+        for (; k + 3 < cnt; k += 4) {
+            const float4 av = *reinterpret_cast<const float4*>(&xs[buf][k]);
+            const float4 wv = *reinterpret_cast<const float4*>(&ws[buf][k]);
+            acc = fmaf(av.x, wv.x, acc); acc = fmaf(av.y, wv.y, acc);
+            acc = fmaf(av.z, wv.z, acc); acc = fmaf(av.w, wv.w, acc);
+        }
+        for (; k < cnt; ++k) acc = fmaf(xs[buf][k], ws[buf][k], acc);
+    }
+    if (lane == 0) {
+        float v = qnn_epi_value(acc, c, e);
+        if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
+        else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
+        y[t] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // pixel-stationary kernel
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int quad_max_i(int v) {
@@ -931,6 +991,14 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
             launched = true;
             snprintf(name, sizeof(name), "dense_%s", x_store == QNN_STORE_BIN ? "bin" : x_store == QNN_STORE_I4 ? "i4" : "i8");
         }
+    }
+    if (!launched && dense && !e.res && x_store == QNN_STORE_F32 && e.out_store == QNN_STORE_F32 && w->d_wq &&
+        (long)N * g.cout < 2000000000L) {
+        const unsigned blocks = (unsigned)((long)N * g.cout);
+        hipLaunchKernelGGL(k_dense_f32in, dim3(blocks), dim3(64), 0, s, e, N, g.cin, g.cout,
+                           (const float*)x, w->d_wq, (float*)y);
+        launched = true;
+        snprintf(name, sizeof(name), "dense_f32");
     }
     if (!launched && pref != 1 && !dense)          // residual epilogues: only where the MFMA kernel has one
         launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
