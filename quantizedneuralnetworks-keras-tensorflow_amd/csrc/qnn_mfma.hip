@@ -1471,6 +1471,217 @@ int launch_areg(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8
     return 1;
 }
 
+// ---------------------------------------------------------------------------------
+// Small-channel 3x3 layers (Cin = 16 or 32, int4 in, int4 out: the 224x224 and 112x112
+// stages of the ResNet): v_mfma_i32_16x16x64_i8 with BOTH operands in registers, no LDS.
+//
+// A 64-deep K-step covers 64 / Cin taps of one 16-pixel row segment: lane (r = lane & 15,
+// kq = lane >> 4) supplies the sixteen channels kq selects of pixel r -- one contiguous
+// 8-byte chunk of the NHWC tensor (Cin = 16: the whole tap kq; Cin = 32: half (kq & 1) of
+// tap (kq >> 1)), fetched with one buffer load and widened to int8 in registers.  The
+// filters of the wave's 16 x NT outputs for ALL K-steps stay in VGPRs (12 / 40 registers).
+// A wave owns four consecutive row segments (64 pixels), its operand registers are
+// refilled for the next tile right after they have been consumed (prefetch distance =
+// one tile), SAME padding = per-(segment, K-step) scalar lane masks assembled from five
+// constant masks per K-step (tap exists / tap in the row above / below / left-edge lane /
+// right-edge lane) and the segment's scalar border flags.
+// Epilogue: BN -> [residual merge: the shortcut word of this lane's OUTPUT position is
+// loaded and nibble-transposed back, so every lane gets its channel's eight shortcut
+// codes from one load] -> clip -> code -> nibble transpose -> one word per lane.
+template <int CIN, int NT>
+__global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs e,
+                                                            const uint8_t* __restrict__ x,
+                                                            const uint8_t* __restrict__ wq8,
+                                                            void* __restrict__ y, int nsegs,
+                                                            int ntiles, FastDiv fd_spr, int spr,
+                                                            uint32_t y_bytes) {
+    constexpr int TAPS = 9;
+    constexpr int KS = (TAPS * CIN + 63) / 64;          // 3 (Cin 16), 5 (Cin 32)
+    constexpr int TPS = 64 / CIN;                        // taps per K-step: 4 / 2
+    constexpr int LPT = 4 / TPS;                         // 16-lane groups per tap: 1 / 2
+    constexpr int MT = 4;                                // row segments per wave tile
+    constexpr int PIXB = CIN / 2;                        // bytes per pixel (int4)
+    const ConvGeom& g = mg.g;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nbase = blockIdx.y * (16 * NT);
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(x), 0, (int)mg.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(e.res ? e.res : (const void*)y), 0, (int)y_bytes, 0x00020000);
+
+    // ---- per-lane K-slot constants, filters, constant lane masks ----
+    int loff[KS];                                       // byte offset from the segment's first pixel
+    v4i bw[KS][NT];
+    unsigned long long m_ok[KS], m_dy0[KS], m_dy2[KS], m_el[KS], m_er[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int tap = ks * TPS + kq / LPT;
+        const int sub = kq % LPT;
+        const bool tok = tap < TAPS;
+        const int dy = tok ? tap / 3 : 1, dx = tok ? tap % 3 : 1;
+        loff[ks] = ((dy - 1) * g.W + (dx - 1) + r) * PIXB + sub * 8;
+        m_ok[ks] = __ballot(tok);
+        m_dy0[ks] = __ballot(tok && dy == 0);
+        m_dy2[ks] = __ballot(tok && dy == 2);
+        m_el[ks] = __ballot(tok && dx == 0 && r == 0);
+        m_er[ks] = __ballot(tok && dx == 2 && r == 15);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int woff = tok ? ((nbase + nt * 16 + r) * TAPS + tap) * CIN + sub * 16 : (int)0x80000000;
+            bw[ks][nt] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
+        }
+    }
+
+    // ---- epilogue constants ----
+    const bool binary = e.fn == QNN_FN_BINARY_TANH;
+    const bool has_res = e.res != nullptr;
+    const float mfold = (!binary && !has_res) ? e.act_m : 1.0f;
+    const float mlate = (!binary && has_res) ? e.act_m : 1.0f;
+    LaneEpi ke;
+    lane_epi_init<QNN_STORE_I4>(ke, e, nbase + r, r);
+    FoldEpi fe[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        LaneEpi kb;
+        lane_epi_init<QNN_STORE_I4>(kb, e, nbase + nt * 16 + r, r);
+        fe[nt].nb = __fdiv_rn(kb.bias, e.scale);
+        fe[nt].ninv = __fmul_rn(__fmul_rn(kb.inv, e.scale), mfold);
+        fe[nt].nshift = __fmul_rn(kb.shift, mfold);
+    }
+    // after the nibble transpose this lane holds the word of value j = r & 7: segment pair member
+    // (j >> 2), pixel 4*kq + (j & 3) of that segment, channels (r & 8) .. +7 of its 16-column tile
+    const int jv = r & 7;
+    const int out_px = 4 * kq + (jv & 3);
+    const int out_cw = (nbase + (r & 8)) >> 3;            // + 2*nt
+
+    // ---- tiles of this wave (XCD-contiguous ranges, waves interleaved) ----
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t_stride = (gridDim.x >> 3) * 4;
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int t_end = min((xcd + 1) * per_xcd, ntiles);
+    int t = xcd * per_xcd + idx * 4 + wave;
+    if (t >= t_end) return;
+
+    // segment decode (all scalar): first pixel index, border flags
+    struct Seg { int px0; bool ok, top, bot, left, right; };
+    auto decode = [&](int tile, int mt) {
+        Seg sg;
+        const int seg = tile * MT + mt;
+        sg.ok = tile < t_end && seg < nsegs;
+        const uint32_t row = qnn_div((uint32_t)seg, fd_spr);          // n*H + y
+        const int xs = (seg - (int)row * spr) * 16;
+        const int n = (int)qnn_div(row, g.fd_hp);                      // Hp == H (no pooling)
+        const int yy = (int)row - n * g.H;
+        sg.px0 = (int)row * g.W + xs;
+        sg.top = yy == 0; sg.bot = yy == g.H - 1; sg.left = xs == 0; sg.right = xs + 16 == g.W;
+        return sg;
+    };
+    uint2 R[KS][MT];
+    auto issue = [&](const Seg& sg, int ks, int mt) {
+        unsigned long long m = m_ok[ks];
+        m &= ~((sg.top ? m_dy0[ks] : 0ull) | (sg.bot ? m_dy2[ks] : 0ull) |
+               (sg.left ? m_el[ks] : 0ull) | (sg.right ? m_er[ks] : 0ull));
+        if (!sg.ok) m = 0ull;
+        const bool ok = __builtin_amdgcn_inverse_ballot_w64(m);
+        const int voff = ok ? loff[ks] + sg.px0 * PIXB : (int)0x80000000;   // out of range -> zeros
+        R[ks][mt] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0));
+    };
+    auto operand = [&](const uint2& q) -> v4i {
+        const uint4 v = make_uint4((q.x << 4) & 0xF0F0F0F0u, q.x & 0xF0F0F0F0u,
+                                   (q.y << 4) & 0xF0F0F0F0u, q.y & 0xF0F0F0F0u);
+        return __builtin_bit_cast(v4i, v);
+    };
+    auto bn = [&](int v, const FoldEpi& f) {
+        return __fadd_rn(__fmul_rn(__fadd_rn((float)v, f.nb), f.ninv), f.nshift);
+    };
+
+    Seg cur[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) cur[mt] = decode(t, mt);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) issue(cur[mt], ks, mt);
+
+    for (; t < t_end; t += t_stride) {
+        Seg nxt[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) nxt[mt] = decode(t + t_stride, mt);
+        v4i acc[MT][NT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const v4i fa = operand(R[ks][mt]);
+                issue(nxt[mt], ks, mt);                   // the registers are free again: next tile
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (ks == 0) {
+                        const v4i z = {0, 0, 0, 0};
+                        acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, bw[ks][nt], z, 0, 0, 0);
+                    } else {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, bw[ks][nt], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        // ---- epilogue: C/D layout of 16x16: column r = output channel, rows 4*kq + i = pixels ----
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mp = 0; mp < MT / 2; ++mp) {
+                float t8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t8[j] = bn(acc[2 * mp + (j >> 2)][nt][j & 3], fe[nt]);
+                const Seg& so = (jv >> 2) ? cur[2 * mp + 1] : cur[2 * mp];
+                const int widx = ((jv >> 2) ? cur[2 * mp + 1].px0 : cur[2 * mp].px0);
+                const bool sok = (jv >> 2) ? cur[2 * mp + 1].ok : cur[2 * mp].ok;
+                (void)so;
+                const int woff = sok ? ((widx + out_px) * e.ocw + out_cw + 2 * nt) * 4 : (int)0x80000000;
+                if (has_res) {
+                    const uint32_t rw = __builtin_amdgcn_raw_buffer_load_b32(rrsrc, woff, 0, 0);
+                    const uint32_t rt = transpose_nib8(rw, ke);    // nibble k = shortcut code of value k, this channel
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int code = (int)(rt << (28 - 4 * j)) >> 28;
+                        const float rv = __fmul_rn((float)code, e.res_scale);
+                        t8[j] = __fmul_rn(__fmul_rn(__fadd_rn(rv, t8[j]), e.post_scale), mlate);
+                    }
+                }
+                const uint32_t P = pack_scaled<4, 8>(t8, e.act_m, binary);
+                const uint32_t Wd = transpose_nib8(P, ke) ^ 0x88888888u;
+                __builtin_amdgcn_raw_buffer_store_b32(Wd, yrsrc, woff, 0, 0);   // out of range: dropped
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) cur[mt] = nxt[mt];
+    }
+}
+
+template <int CIN, int NT>
+int launch_small(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
+                 hipStream_t s) {
+    const ConvGeom& g = mg.g;
+    const int spr = g.W / 16;
+    const long nsegs_l = (long)g.N * g.H * spr;
+    const double ybytes = (double)g.N * g.H * g.W * e.ocw * 4.0;
+    if (nsegs_l >= 2000000000L || ybytes >= 2.0e9) return 1;
+    const int nsegs = (int)nsegs_l;
+    const int ntiles = (nsegs + 3) / 4;
+    const int ny = g.cout / (16 * NT);
+    int gx = (((ntiles + 3) / 4 + 7) / 8) * 8;
+    const int cap = ((512 / ny + 7) / 8) * 8;               // two resident workgroups per CU
+    if (gx > cap) gx = cap;
+    const dim3 grid((unsigned)gx, (unsigned)ny), block(256);
+    hipLaunchKernelGGL((k_conv_mfma_small<CIN, NT>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y,
+                       nsegs, ntiles, qnn_fastdiv((uint32_t)spr), spr, (uint32_t)ybytes);
+    return 0;
+}
+
 template <int XS, int OUT>
 void launch_wres_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
                       hipStream_t s) {
@@ -1994,7 +2205,9 @@ __global__ __launch_bounds__(256) void k_expand_i4_weights(const uint32_t* __res
 // Build the int8 weight image the MFMA kernel reads (called from qnn_prepack_weights).
 int qnn_mfma_prepare_weights(qnn_weights* w, hipStream_t s) {
     w->d_mfma = nullptr;
-    if (w->cin % 64 != 0 || w->cout % 64 != 0) return QNN_OK;
+    const bool small = w->store == QNN_STORE_I4 && (w->cin == 16 || w->cin == 32) && (w->cout % 16) == 0 &&
+                       w->kh == 3 && w->kw == 3;
+    if (!small && (w->cin % 64 != 0 || w->cout % 64 != 0)) return QNN_OK;
     if (w->store == QNN_STORE_I8) {
         w->d_mfma = (uint8_t*)w->d_packed;      // int8 codes, natural channel order
         return QNN_OK;
@@ -2036,6 +2249,25 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     }
     if (!w->d_mfma) return 1;
     if (x_store != QNN_STORE_I8 && x_store != QNN_STORE_I4) return 1;
+    // small-channel 3x3 int4 layers: both operands in registers
+    if (x_store == QNN_STORE_I4 && w->store == QNN_STORE_I4 && (g.cin == 16 || g.cin == 32) && g.kh == 3 &&
+        g.kw == 3 && g.stride == 1 && g.pt == 1 && g.pl == 1 && g.pool == 1 && (g.W % 16) == 0 &&
+        e.out_store == QNN_STORE_I4 && (g.cout % (g.cin == 16 ? 16 : 32)) == 0 &&
+        (!e.res || (e.res_store == QNN_STORE_I4 && e.res_cw == e.ocw)) && !getenv("QNN_MFMA_SMALL_OFF")) {
+        MfmaGeom ms;
+        ms.g = g; ms.kc = 1; ms.steps = 0; ms.x_pix_bytes = g.cin / 2;
+        ms.total_q = (long)g.N * g.H * g.W;
+        const double xb_ = (double)g.N * g.H * g.W * ms.x_pix_bytes, wb_ = (double)g.cout * 9 * g.cin;
+        if (xb_ < 2.0e9 && wb_ < 2.0e9) {
+            ms.x_bytes = (uint32_t)xb_; ms.w_bytes = (uint32_t)wb_; ms.ablate = 0;
+            EpiArgs es = e;
+            es.scale = e.scale * (1.0f / 256.0f);            // both operands carry *16
+            snprintf(name, name_len, "mfma_i4_small_c%d", g.cin);
+            const int rc_ = g.cin == 16 ? launch_small<16, 1>(ms, es, x, w->d_mfma, y, s)
+                                        : launch_small<32, 2>(ms, es, x, w->d_mfma, y, s);
+            if (rc_ == 0) return 0;
+        }
+    }
     if (g.cin % 64 != 0 || g.cout % 64 != 0) return 1;
     const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
     if (g.cout % pw != 0) return 1;

@@ -474,6 +474,25 @@ def test_one_bit_layers_on_the_matrix_pipe():
         _abi.set_conv_impl(_abi.IMPL_AUTO)
 
 
+@pytest.mark.parametrize("cin,cout,hw,n", [(16, 16, (20, 32), 3), (16, 32, (7, 16), 2), (32, 32, (9, 16), 5),
+                                           (32, 64, (5, 48), 2), (16, 16, (33, 16), 9)])
+def test_small_channel_layers_on_the_matrix_pipe(cin, cout, hw, n):
+    """3x3 int4 layers with 16 / 32 input channels: both MFMA operands in registers (no LDS);
+    ragged tile counts, every border class, 2- and 4-bit and binary output codes."""
+    rng = np.random.default_rng(cin * 1000 + cout + hw[0])
+    H, W = hw
+    pre = rng.standard_normal((n, H, W, cin)).astype(F32)
+    x = O.run_spec([Q(4)], pre)
+    op = {"op": "conv", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (3, 3, cin, cout)).astype(F32),
+          "bias": (rng.standard_normal(cout) * 0.05).astype(F32), "strides": (1, 1), "padding": "same"}
+    bn = _rand_bn(rng, cout, 9 * cin * 0.12)
+    for act in (Q(4), Q(2), BIN_ACT):
+        want = _oracle_group(x, op, bn, act, 1)
+        got, kern = _run_group(x, Q(4), op, bn, act, 1, _abi.STORE_I4)
+        assert kern == "mfma_i4_small_c%d" % cin, kern
+        np.testing.assert_array_equal(got, want)
+
+
 def test_vgg_large_8bit_small_batch(impl):
     cf = nets.baseline_config(3)
     spec = nets.build_spec(cf, nets.SEED_BASE + 3)
@@ -539,6 +558,13 @@ def test_residual_fused_model(nt, wb, ab, nres):
         np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec[:-1])(dev(x))), env[logits_name])
         assert "generic" not in m.kernel_log, m.kernel_log
         assert len(m.kernel_log) == sum(op["op"] == "conv" for op in spec)
+        if (nt, wb, ab) == ("full-qnn", 4, 4):
+            # the 16- and 32-channel stages (incl. their residual merges) run on the register-operand
+            # MFMA kernel, the 64-channel stage on the LDS-weights one
+            assert m.kernel_log.count("mfma_i4_small_c16") >= 2 * nres, m.kernel_log
+            # (the first 32-channel block starts with a stride-2 conv and merges a float32 projection)
+            assert m.kernel_log.count("mfma_i4_small_c32") >= 2 * (nres - 1), m.kernel_log
+            assert any(k.startswith("mfma_i4_areg") for k in m.kernel_log), m.kernel_log
 
 
 @pytest.mark.parametrize("code,wb,ab", [("44", 4, 4), ("bb", None, None)])
