@@ -26,6 +26,9 @@
 #include <type_traits>
 
 #include "qnn_common.h"
+#ifndef QNN_SMALL16_WPC
+#define QNN_SMALL16_WPC 4
+#endif
 #ifndef QNN_FIRST_WPS
 #define QNN_FIRST_WPS 3
 #endif
@@ -1489,7 +1492,7 @@ int launch_areg(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8
 // loaded and nibble-transposed back, so every lane gets its channel's eight shortcut
 // codes from one load] -> clip -> code -> nibble transpose -> one word per lane.
 template <int CIN, int NT>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs e,
+__global__ __launch_bounds__(256, (CIN == 16 ? QNN_SMALL16_WPC : 2)) void k_conv_mfma_small(MfmaGeom mg, EpiArgs e,
                                                             const uint8_t* __restrict__ x,
                                                             const uint8_t* __restrict__ wq8,
                                                             void* __restrict__ y, int nsegs,
@@ -1518,7 +1521,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs
     // ---- per-lane K-slot constants, filters, constant lane masks ----
     int loff[KS];                                       // byte offset from the segment's first pixel
     v4i bw[KS][NT];
+    // SAME padding: Cin 16 keeps five constant 64-bit lane masks per K-step in SGPRs and assembles a
+    // load's mask with scalar ops; with five K-steps (Cin 32) those 50 SGPRs made the compiler spill
+    // scalars into VGPR lanes, so there the same facts sit in one per-lane bit word per K-step
+    // (bit 1 tap above, 2 below, 3 left-edge lane, 4 right-edge lane, 5 no such tap, 6 always) that
+    // is ANDed with the segment's scalar flag word
+    constexpr bool SMASK = CIN == 16;
     unsigned long long m_ok[KS], m_dy0[KS], m_dy2[KS], m_el[KS], m_er[KS];
+    int lbits[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int tap = ks * TPS + kq / LPT;
@@ -1526,11 +1536,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs
         const bool tok = tap < TAPS;
         const int dy = tok ? tap / 3 : 1, dx = tok ? tap % 3 : 1;
         loff[ks] = ((dy - 1) * g.W + (dx - 1) + r) * PIXB + sub * 8;
-        m_ok[ks] = __ballot(tok);
-        m_dy0[ks] = __ballot(tok && dy == 0);
-        m_dy2[ks] = __ballot(tok && dy == 2);
-        m_el[ks] = __ballot(tok && dx == 0 && r == 0);
-        m_er[ks] = __ballot(tok && dx == 2 && r == 15);
+        if constexpr (SMASK) {
+            m_ok[ks] = __ballot(tok);
+            m_dy0[ks] = __ballot(tok && dy == 0);
+            m_dy2[ks] = __ballot(tok && dy == 2);
+            m_el[ks] = __ballot(tok && dx == 0 && r == 0);
+            m_er[ks] = __ballot(tok && dx == 2 && r == 15);
+        } else {
+            lbits[ks] = (tok && dy == 0 ? 2 : 0) | (tok && dy == 2 ? 4 : 0) | (tok && dx == 0 && r == 0 ? 8 : 0) |
+                        (tok && dx == 2 && r == 15 ? 16 : 0) | (tok ? 0 : 32) | 64;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int woff = tok ? ((nbase + nt * 16 + r) * TAPS + tap) * CIN + sub * 16 : (int)0x80000000;
@@ -1568,28 +1583,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs
     int t = xcd * per_xcd + idx * 4 + wave;
     if (t >= t_end) return;
 
-    // segment decode (all scalar): first pixel index, border flags
-    struct Seg { int px0; bool ok, top, bot, left, right; };
-    auto decode = [&](int tile, int mt) {
-        Seg sg;
+    // segment decode (all scalar): first pixel index and border flags packed into one word
+    // (bit 0 valid, 1 top row, 2 bottom row, 3 left edge, 4 right edge) -- few live SGPRs matter
+    // here: with one struct of booleans per segment the compiler spilled scalars into VGPR lanes
+    auto decode = [&](int tile, int mt, int& px0) -> int {
         const int seg = tile * MT + mt;
-        sg.ok = tile < t_end && seg < nsegs;
+        const bool ok = tile < t_end && seg < nsegs;
         const uint32_t row = qnn_div((uint32_t)seg, fd_spr);          // n*H + y
         const int xs = (seg - (int)row * spr) * 16;
         const int n = (int)qnn_div(row, g.fd_hp);                      // Hp == H (no pooling)
         const int yy = (int)row - n * g.H;
-        sg.px0 = (int)row * g.W + xs;
-        sg.top = yy == 0; sg.bot = yy == g.H - 1; sg.left = xs == 0; sg.right = xs + 16 == g.W;
-        return sg;
+        px0 = (int)row * g.W + xs;
+        return (ok ? 1 : 0) | (yy == 0 ? 2 : 0) | (yy == g.H - 1 ? 4 : 0) | (xs == 0 ? 8 : 0) |
+               (xs + 16 == g.W ? 16 : 0);
     };
     uint2 R[KS][MT];
-    auto issue = [&](const Seg& sg, int ks, int mt) {
-        unsigned long long m = m_ok[ks];
-        m &= ~((sg.top ? m_dy0[ks] : 0ull) | (sg.bot ? m_dy2[ks] : 0ull) |
-               (sg.left ? m_el[ks] : 0ull) | (sg.right ? m_er[ks] : 0ull));
-        if (!sg.ok) m = 0ull;
-        const bool ok = __builtin_amdgcn_inverse_ballot_w64(m);
-        const int voff = ok ? loff[ks] + sg.px0 * PIXB : (int)0x80000000;   // out of range -> zeros
+    auto issue = [&](int px0, int fl, int ks, int mt) {
+        bool ok;
+        if constexpr (SMASK) {
+            unsigned long long m = m_ok[ks];
+            m &= ~(((fl & 2) ? m_dy0[ks] : 0ull) | ((fl & 4) ? m_dy2[ks] : 0ull) |
+                   ((fl & 8) ? m_el[ks] : 0ull) | ((fl & 16) ? m_er[ks] : 0ull));
+            if (!(fl & 1)) m = 0ull;
+            ok = __builtin_amdgcn_inverse_ballot_w64(m);
+        } else {
+            const int sbits = (fl & 0x1E) | 32 | ((fl & 1) ? 0 : 64);
+            ok = (lbits[ks] & sbits) == 0;
+        }
+        const int voff = ok ? loff[ks] + px0 * PIXB : (int)0x80000000;   // out of range -> zeros
         R[ks][mt] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0));
     };
     auto operand = [&](const uint2& q) -> v4i {
@@ -1601,25 +1622,37 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs
         return __fadd_rn(__fmul_rn(__fadd_rn((float)v, f.nb), f.ninv), f.nshift);
     };
 
-    Seg cur[MT];
+    int cur_px0[MT], cur_fl[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) cur[mt] = decode(t, mt);
+    for (int mt = 0; mt < MT; ++mt) {
+        cur_fl[mt] = decode(t, mt, cur_px0[mt]);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) issue(cur[mt], ks, mt);
+        for (int ks = 0; ks < KS; ++ks) issue(cur_px0[mt], cur_fl[mt], ks, mt);
+    }
 
     for (; t < t_end; t += t_stride) {
-        Seg nxt[MT];
+        // output word of this lane per segment pair (also the address of its shortcut word, which is
+        // requested now so that the round trip hides behind the MFMA phase)
+        int woff[MT / 2];
+        uint32_t rw[NT][MT / 2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) nxt[mt] = decode(t + t_stride, mt);
+        for (int mp = 0; mp < MT / 2; ++mp) {
+            const int px0 = (jv >> 2) ? cur_px0[2 * mp + 1] : cur_px0[2 * mp];
+            const bool sok = ((jv >> 2) ? cur_fl[2 * mp + 1] : cur_fl[2 * mp]) & 1;
+            woff[mp] = sok ? ((px0 + out_px) * e.ocw + out_cw) * 4 : (int)0x80000000;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                rw[nt][mp] = has_res ? __builtin_amdgcn_raw_buffer_load_b32(rrsrc, woff[mp] + 8 * nt, 0, 0) : 0u;
+        }
         v4i acc[MT][NT];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int mt = 0; mt < MT; ++mt) {
+            int npx0;
+            const int nfl = decode(t + t_stride, mt, npx0);     // this segment of the NEXT tile
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const v4i fa = operand(R[ks][mt]);
-                issue(nxt[mt], ks, mt);                   // the registers are free again: next tile
+                issue(npx0, nfl, ks, mt);                 // the registers are free again: next tile
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     if (ks == 0) {
@@ -1630,6 +1663,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs
                     }
                 }
             }
+            cur_px0[mt] = npx0;                            // (the epilogue below uses woff, computed above)
+            cur_fl[mt] = nfl;
+        }
         // ---- epilogue: C/D layout of 16x16: column r = output channel, rows 4*kq + i = pixels ----
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -1638,14 +1674,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs
                 float t8[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) t8[j] = bn(acc[2 * mp + (j >> 2)][nt][j & 3], fe[nt]);
-                const Seg& so = (jv >> 2) ? cur[2 * mp + 1] : cur[2 * mp];
-                const int widx = ((jv >> 2) ? cur[2 * mp + 1].px0 : cur[2 * mp].px0);
-                const bool sok = (jv >> 2) ? cur[2 * mp + 1].ok : cur[2 * mp].ok;
-                (void)so;
-                const int woff = sok ? ((widx + out_px) * e.ocw + out_cw + 2 * nt) * 4 : (int)0x80000000;
                 if (has_res) {
-                    const uint32_t rw = __builtin_amdgcn_raw_buffer_load_b32(rrsrc, woff, 0, 0);
-                    const uint32_t rt = transpose_nib8(rw, ke);    // nibble k = shortcut code of value k, this channel
+                    const uint32_t rt = transpose_nib8(rw[nt][mp], ke);   // nibble k = shortcut code of value k, this channel
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int code = (int)(rt << (28 - 4 * j)) >> 28;
@@ -1655,10 +1685,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_small(MfmaGeom mg, EpiArgs
                 }
                 const uint32_t P = pack_scaled<4, 8>(t8, e.act_m, binary);
                 const uint32_t Wd = transpose_nib8(P, ke) ^ 0x88888888u;
-                __builtin_amdgcn_raw_buffer_store_b32(Wd, yrsrc, woff, 0, 0);   // out of range: dropped
+                __builtin_amdgcn_raw_buffer_store_b32(Wd, yrsrc, woff[mp] + 8 * nt, 0, 0);   // out of range: dropped
             }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) cur[mt] = nxt[mt];
     }
 }
 
@@ -1674,7 +1702,8 @@ int launch_small(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     const int ntiles = (nsegs + 3) / 4;
     const int ny = g.cout / (16 * NT);
     int gx = (((ntiles + 3) / 4 + 7) / 8) * 8;
-    const int cap = ((512 / ny + 7) / 8) * 8;               // two resident workgroups per CU
+    const int wpc = CIN == 16 ? QNN_SMALL16_WPC : 2;         // resident workgroups per CU (register budget)
+    const int cap = ((256 * wpc / ny + 7) / 8) * 8;
     if (gx > cap) gx = cap;
     const dim3 grid((unsigned)gx, (unsigned)ny), block(256);
     hipLaunchKernelGGL((k_conv_mfma_small<CIN, NT>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y,
