@@ -29,6 +29,9 @@
 #ifndef QNN_SMALL16_WPC
 #define QNN_SMALL16_WPC 4
 #endif
+#ifndef QNN_SMALL32_WPC
+#define QNN_SMALL32_WPC 2
+#endif
 #ifndef QNN_FIRST_WPS
 #define QNN_FIRST_WPS 3
 #endif
@@ -1492,7 +1495,7 @@ int launch_areg(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8
 // loaded and nibble-transposed back, so every lane gets its channel's eight shortcut
 // codes from one load] -> clip -> code -> nibble transpose -> one word per lane.
 template <int CIN, int NT>
-__global__ __launch_bounds__(256, (CIN == 16 ? QNN_SMALL16_WPC : 2)) void k_conv_mfma_small(MfmaGeom mg, EpiArgs e,
+__global__ __launch_bounds__(256, (CIN == 16 ? QNN_SMALL16_WPC : QNN_SMALL32_WPC)) void k_conv_mfma_small(MfmaGeom mg, EpiArgs e,
                                                             const uint8_t* __restrict__ x,
                                                             const uint8_t* __restrict__ wq8,
                                                             void* __restrict__ y, int nsegs,
@@ -1702,7 +1705,7 @@ int launch_small(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     const int ntiles = (nsegs + 3) / 4;
     const int ny = g.cout / (16 * NT);
     int gx = (((ntiles + 3) / 4 + 7) / 8) * 8;
-    const int wpc = CIN == 16 ? QNN_SMALL16_WPC : 2;         // resident workgroups per CU (register budget)
+    const int wpc = CIN == 16 ? QNN_SMALL16_WPC : QNN_SMALL32_WPC;   // resident workgroups per CU (register budget)
     const int cap = ((256 * wpc / ny + 7) / 8) * 8;
     if (gx > cap) gx = cap;
     const dim3 grid((unsigned)gx, (unsigned)ny), block(256);
