@@ -83,6 +83,11 @@ def main():
     # single rank -- the only way to exercise the RCCL calls on a 1-GPU box
     use_dist = world > 1 or os.environ.get("QNN_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        # stdout carries exactly one JSON line: keep RCCL's version / host banner (NCCL_DEBUG=VERSION|INFO
+        # prints it to stdout at init) off it unless asked otherwise
+        if os.environ.get("QNN_KEEP_NCCL_DEBUG") != "1" and \
+                os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "TRACE"):
+            os.environ["NCCL_DEBUG"] = "WARN"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend, rank=rank, world_size=world)
