@@ -82,12 +82,13 @@ def main():
     # QNN_BENCH_FORCE_DIST=1: run the N>1 code path (process group, logits all-gather) with a
     # single rank -- the only way to exercise the RCCL calls on a 1-GPU box
     use_dist = world > 1 or os.environ.get("QNN_BENCH_FORCE_DIST") == "1"
+    json_fd = None
     if use_dist:
-        # stdout carries exactly one JSON line: keep RCCL's version / host banner (NCCL_DEBUG=VERSION|INFO
-        # prints it to stdout at init) off it unless asked otherwise
-        if os.environ.get("QNN_KEEP_NCCL_DEBUG") != "1" and \
-                os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO", "TRACE"):
-            os.environ["NCCL_DEBUG"] = "WARN"
+        # stdout carries exactly one JSON line, but RCCL writes its banner and warnings to file
+        # descriptor 1: point fd 1 at stderr for the whole run and keep the real stdout for the result
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -320,7 +321,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(cf, spec)
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"error": str(exc)}
-        print(json.dumps(out))
+        line = json.dumps(out) + "\n"
+        if json_fd is None:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            os.write(json_fd, line.encode())
     if use_dist:
         dist.destroy_process_group()
 
