@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_SMALL16_WPC : QNN_SMALL32_WPC
                                                             const uint8_t* __restrict__ wq8,
                                                             void* __restrict__ y, int nsegs,
                                                             int ntiles, FastDiv fd_spr, int spr,
-                                                            uint32_t y_bytes) {
+                                                            uint32_t y_bytes, uint32_t res_bytes) {
     constexpr int TAPS = 9;
     constexpr int KS = (TAPS * CIN + 63) / 64;          // 3 (Cin 16), 5 (Cin 32)
     constexpr int TPS = 64 / CIN;                        // taps per K-step: 4 / 2
@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_SMALL16_WPC : QNN_SMALL32_WPC
         const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(e.res ? e.res : (const void*)y), 0, (int)y_bytes, 0x00020000);
+        const_cast<void*>(e.res ? e.res : (const void*)y), 0, (int)res_bytes, 0x00020000);
 
     // ---- per-lane K-slot constants, filters, constant lane masks ----
     int loff[KS];                                       // byte offset from the segment's first pixel
@@ -1559,6 +1559,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_SMALL16_WPC : QNN_SMALL32_WPC
     // ---- epilogue constants ----
     const bool binary = e.fn == QNN_FN_BINARY_TANH;
     const bool has_res = e.res != nullptr;
+    const bool res_f32 = has_res && e.res_store == QNN_STORE_F32;   // a float32 projection shortcut
     const float mfold = (!binary && !has_res) ? e.act_m : 1.0f;
     const float mlate = (!binary && has_res) ? e.act_m : 1.0f;
     LaneEpi ke;
@@ -1645,8 +1646,13 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_SMALL16_WPC : QNN_SMALL32_WPC
             woff[mp] = sok ? ((px0 + out_px) * e.ocw + out_cw) * 4 : (int)0x80000000;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                rw[nt][mp] = has_res ? __builtin_amdgcn_raw_buffer_load_b32(rrsrc, woff[mp] + 8 * nt, 0, 0) : 0u;
+                rw[nt][mp] = (has_res && !res_f32) ? __builtin_amdgcn_raw_buffer_load_b32(rrsrc, woff[mp] + 8 * nt, 0, 0) : 0u;
         }
+        // float32 shortcut: byte offset of (first pixel of the lane's row group, its channel) per segment
+        int foff[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            foff[mt] = (res_f32 && (cur_fl[mt] & 1)) ? ((cur_px0[mt] + 4 * kq) * g.cout + nbase + r) * 4 : (int)0x80000000;
         v4i acc[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -1677,7 +1683,14 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_SMALL16_WPC : QNN_SMALL32_WPC
                 float t8[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) t8[j] = bn(acc[2 * mp + (j >> 2)][nt][j & 3], fe[nt]);
-                if (has_res) {
+                if (res_f32) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float rv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            rrsrc, foff[2 * mp + (j >> 2)] + ((j & 3) * g.cout + nt * 16) * 4, 0, 0));
+                        t8[j] = __fmul_rn(__fmul_rn(__fadd_rn(rv, t8[j]), e.post_scale), mlate);
+                    }
+                } else if (has_res) {
                     const uint32_t rt = transpose_nib8(rw[nt][mp], ke);   // nibble k = shortcut code of value k, this channel
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -1709,8 +1722,10 @@ int launch_small(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     const int cap = ((256 * wpc / ny + 7) / 8) * 8;
     if (gx > cap) gx = cap;
     const dim3 grid((unsigned)gx, (unsigned)ny), block(256);
+    const double rbytes = e.res && e.res_store == QNN_STORE_F32 ? (double)g.N * g.H * g.W * g.cout * 4.0 : ybytes;
+    if (rbytes >= 2.0e9) return 1;
     hipLaunchKernelGGL((k_conv_mfma_small<CIN, NT>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y,
-                       nsegs, ntiles, qnn_fastdiv((uint32_t)spr), spr, (uint32_t)ybytes);
+                       nsegs, ntiles, qnn_fastdiv((uint32_t)spr), spr, (uint32_t)ybytes, (uint32_t)rbytes);
     return 0;
 }
 
@@ -2285,7 +2300,8 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     if (x_store == QNN_STORE_I4 && w->store == QNN_STORE_I4 && (g.cin == 16 || g.cin == 32) && g.kh == 3 &&
         g.kw == 3 && g.stride == 1 && g.pt == 1 && g.pl == 1 && g.pool == 1 && (g.W % 16) == 0 &&
         e.out_store == QNN_STORE_I4 && (g.cout % (g.cin == 16 ? 16 : 32)) == 0 &&
-        (!e.res || (e.res_store == QNN_STORE_I4 && e.res_cw == e.ocw)) && !getenv("QNN_MFMA_SMALL_OFF")) {
+        (!e.res || (e.res_store == QNN_STORE_I4 && e.res_cw == e.ocw) ||
+         (e.res_store == QNN_STORE_F32 && e.res_cw == g.cout)) && !getenv("QNN_MFMA_SMALL_OFF")) {
         MfmaGeom ms;
         ms.g = g; ms.kc = 1; ms.steps = 0; ms.x_pix_bytes = g.cin / 2;
         ms.total_q = (long)g.N * g.H * g.W;
