@@ -568,6 +568,23 @@ def test_residual_fused_model(nt, wb, ab, nres):
             assert any(k.startswith("mfma_i4_areg") for k in m.kernel_log), m.kernel_log
 
 
+def test_residual_fused_model_at_imagenet_geometry():
+    """224 / 112 / 56 wide stages (14 / 7 / 3.5 sixteen-pixel segments per row, tiles straddling rows and
+    images): every matrix-pipe kernel of the residual engine against the oracle, bit for bit."""
+    base = nets.baseline_config(4)
+    cf = nets.Config(network_type=base.network_type, wbits=base.wbits, abits=base.abits, architecture="RESNET",
+                     nres=2, dim=base.dim, channels=base.channels, classes=base.classes)
+    spec = nets.build_spec(cf, 11)[:-1]                     # logits
+    x = nets.synthetic_images(cf, 2, 12)
+    want = O.run_spec(spec, x, float_conv="device")
+    m = engine.ResidualFusedModel(spec)
+    m.kernel_log = []
+    got = host(m(dev(x)))
+    np.testing.assert_array_equal(got, want)
+    for k in ("mfma_i4_small_c16", "mfma_i4_small_c32", "mfma_i4_areg64x64"):
+        assert k in m.kernel_log, m.kernel_log
+
+
 @pytest.mark.parametrize("code,wb,ab", [("44", 4, 4), ("bb", None, None)])
 def test_residual_fused_model_on_trained_checkpoint(code, wb, ab):
     spec = nets.spec_from_keras_npz(os.path.join(GOLD, "resnet3_full_%s.npz" % code), wb, ab)
