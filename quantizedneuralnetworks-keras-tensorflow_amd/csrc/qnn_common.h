@@ -157,8 +157,12 @@ __device__ __forceinline__ float qnn_quant_code_f(float x, float m) {
     float rt = __fadd_rn(t, __fsub_rn(r, t));
     return fminf(fmaxf(rt, -m), __fsub_rn(m, 1.0f));
 }
+// m is always 2^(bits-1): dividing by it equals multiplying by its exact reciprocal (one integer
+// subtraction on the exponent field) -- an IEEE divide costs ~10 instructions per value, which made
+// every float32-output epilogue with a fused clip VALU-bound
 __device__ __forceinline__ float qnn_quantized_tanh(float x, float m) {
-    return __fdiv_rn(qnn_quant_code_f(x, m), m);
+    const float inv_m = __uint_as_float(0x7F000000u - __float_as_uint(m));
+    return __fmul_rn(qnn_quant_code_f(x, m), inv_m);
 }
 
 // ---- dot products on packed words ----------------------------------------------
