@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_wres(MfmaGeom mg, EpiArgs 
 // Three workgroups (12 waves) per CU: one wave's staging / epilogue VALU runs under
 // the other waves' MFMAs (int8 MFMA and VALU co-issue on gfx950).
 template <int XS, int OUT, int POOL, int KC>
-__global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs e,
+__global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs e,
                                                            const uint8_t* __restrict__ x,
                                                            const uint8_t* __restrict__ wq8,
                                                            void* __restrict__ y, int ntiles) {
@@ -1340,6 +1340,47 @@ __global__ __launch_bounds__(256, 3) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs 
                         [&](int j) { return row0 + ((j >> 2) * 8 + 2 * (j & 3) + lh); },
                         [&](int) { return c; }, mg.total_q, g.cout, y);
                 }
+            } else if constexpr (OUT == QNN_STORE_F32) {
+                // float32 surface.  Straight-line code: the activation is chosen once per tile (three
+                // copies of the loop) and only the last, partial tile guards its stores -- with a branch per
+                // value the compiler spilled 348 bytes per lane and this path ran 4x slower than the
+                // packed ones.  32-bit offsets from the tile's first pixel, non-temporal stores.
+                float* yt = reinterpret_cast<float*>(y) + row0 * g.cout;
+                const int lbase = 4 * lh * g.cout + c;
+                const int lrem = rem - 4 * lh;
+                auto emit = [&](auto fn_c, auto full_c) {
+                    constexpr int FN = decltype(fn_c)::value;
+                    constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int srow = a * 32 + (r & 3) + 8 * (r >> 2);      // wave-uniform
+                            float v = bn(acc[a][b][r], fe[b]);
+                            if (has_res) {
+                                const long q = row0 + srow + 4 * lh;
+                                if (FULL || srow < lrem) v = __fmul_rn(qnn_epi_residual(v, q, c, e), mlate);
+                            }
+                            if constexpr (FN == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
+                            else if constexpr (FN == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
+                            if (FULL || srow < lrem) __builtin_nontemporal_store(v, &yt[lbase + srow * g.cout]);
+                            // keep the scheduler from hoisting all 64 conversions and addresses of a tile
+                            // in front of the first store (256 VGPRs and spills otherwise)
+                            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                        }
+                };
+                using std::integral_constant;
+                using std::true_type;
+                using std::false_type;
+                if (rem >= TM) {
+                    if (e.fn == QNN_FN_BINARY_TANH) emit(integral_constant<int, QNN_FN_BINARY_TANH>{}, true_type{});
+                    else if (e.fn == QNN_FN_QUANTIZED_TANH) emit(integral_constant<int, QNN_FN_QUANTIZED_TANH>{}, true_type{});
+                    else emit(integral_constant<int, QNN_FN_NONE>{}, true_type{});
+                } else {
+                    if (e.fn == QNN_FN_BINARY_TANH) emit(integral_constant<int, QNN_FN_BINARY_TANH>{}, false_type{});
+                    else if (e.fn == QNN_FN_QUANTIZED_TANH) emit(integral_constant<int, QNN_FN_QUANTIZED_TANH>{}, false_type{});
+                    else emit(integral_constant<int, QNN_FN_NONE>{}, false_type{});
+                }
             } else {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
@@ -1447,7 +1488,8 @@ void launch_areg_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const
     const int ntiles = (int)((rows + 63) / 64);              // 64-row wave tiles
     const int ny = mg.g.cout / 64;
     int gx = (((ntiles + 3) / 4 + 7) / 8) * 8;
-    const int cap = ((768 / ny + 7) / 8) * 8;               // three resident workgroups per CU
+    // three resident workgroups per CU (two for float32 outputs: their 64 stores per tile need more registers)
+    const int cap = (((OUT == QNN_STORE_F32 ? 512 : 768) / ny + 7) / 8) * 8;
     if (gx > cap) gx = cap;
     const dim3 grid((unsigned)gx, (unsigned)ny), block(256);
     const size_t lds = (size_t)9 * KC * 64 * 64;
