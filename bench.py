@@ -1,29 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec @ batch 4096, CIFAR-10 VGG full-qnn 4/4.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--workload ...]
 
-One "step" = one forward pass of the fused low-bit pipeline over one synthetic
-batch of 4096 CIFAR-shaped images per GPU (inputs resident in HBM before the
-timed region), followed -- for N > 1 -- by the RCCL all-gather of the logits.
-Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides
-the throughput, `roofline` (dominant kernel, HIP-event timed inside the timed
-region) and `cpu_baseline` (the restated reference float path on the host cores).
+One "step" = one forward pass of the fused low-bit pipeline over one synthetic batch
+(4096 CIFAR-shaped images per GPU in weak scaling; the 4096-image global batch cut into
+contiguous shards in strong scaling), inputs resident in HBM before the timed region,
+followed -- for N > 1 -- by the RCCL all-gather of the logits.
+
+Launching.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a
+launcher: before anything touches the GPU it starts N fresh child processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), relays rank 0's
+JSON line and exits non-zero if any rank fails.  Under torchrun (WORLD_SIZE set) the process
+is a rank; --gpus must then equal WORLD_SIZE.  Asking for more ranks than the box has GPUs
+is an error unless --rehearse is given (all ranks on the GPUs that exist, gloo exchange).
+
+Timing.  W warm-up steps, then the K-step region -- barrier + torch.cuda.synchronize() on both
+sides, MAX over ranks -- is timed R >= 5 times (more until ~0.3 s have been timed, the region
+of the default workload is only a few ms) and the MEDIAN region gives `ms_per_step` / `value`.
+
+Rank 0 prints ONE JSON line carrying, besides the throughput, `roofline` (dominant kernel,
+HIP-event timed on the stream it is launched on) and `cpu_baseline` (the restated reference
+float path on the host cores, N = 1 only).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 PKG = "quantizedneuralnetworks-keras-tensorflow_amd"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -35,12 +46,99 @@ WORKLOADS = {
     "vgg_large_full_qnn_w8a8": 3,
     "imagenet224_resnet10_w4a4": 4,   # BASELINE.json configs[4]; ResidualFusedModel, 64 images / GPU
 }
+M1_BYTES = {1: 17704, 2: 33832, 3: 1560616, 4: 30307912}       # packed inter-layer traffic per image
+MACS = {1: 13576192, 2: 13576192, 3: 1781309440, 4: 6855277184}
 
 
-def step_bytes(st, N, H, W):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="vgg64_full_qnn_w4a4", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch images per GPU; strong: --batch images in all, cut into contiguous shards")
+    ap.add_argument("--repeats", type=int, default=5, help="minimum number of timed K-step regions (median reported)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="replay the forward from a hipGraph")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches kept in flight: graphs replayed round-robin on as many streams")
+    ap.add_argument("--impl", default="auto", choices=["auto", "valu", "mfma"],
+                    help="conv kernel family (results are bit-identical)")
+    ap.add_argument("--first-layer", default="exact", choices=["exact", "fixed"],
+                    help="float32 first layer: exact FMA chain (default) or the fixed-point int8-limb variant")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="allow more ranks than GPUs (ranks share devices, logits exchanged over gloo)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: runs before anything touches the GPU
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+
+
+def launch_ranks(args, argv):
+    """Start one fresh process per rank; returns the exit status for the launcher."""
+    ndev = visible_gpus()
+    env_extra = {}
+    if ndev < args.gpus:
+        if not args.rehearse:
+            sys.stderr.write("bench.py: --gpus %d but this box has %d GPU(s).  Refusing to report n_gpus=%d from "
+                             "fewer devices (pass --rehearse to run the ranks on the GPUs that exist with a gloo "
+                             "exchange; such a run is a rehearsal of the code path, not a scaling measurement).\n"
+                             % (args.gpus, ndev, args.gpus))
+            return 2
+        if ndev == 0:
+            sys.stderr.write("bench.py: no GPU visible; the product path has no CPU fallback.\n")
+            return 2
+        env_extra["QNN_DIST_BACKEND"] = "gloo"
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env_extra)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].stdout.read()
+    rc = 0
+    deadline = time.time() + 3600
+    for p in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            code = -9
+        if code != 0 and rc == 0:
+            rc = code if code > 0 else 1
+            for q in procs:                   # one rank failed: the others would wait in a collective for ever
+                if q.poll() is None:
+                    q.kill()
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.strip()]
+    if rc == 0 and lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        rc = 1
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+def step_bytes(abi, st, N, H, W):
     """Algorithmic bytes of one fused step under traffic model M1:
     input as stored + output as stored (weights amortise to ~0 at N=4096)."""
-    abi = importlib.import_module(PKG + "._abi")
     kh, kw, cin, cout = st["w"].shape
     if st["kind"] == "conv":
         Ho = abi.out_hw(H, kh, st["w"].stride, st["w"].same_pad) // st["pool"]
@@ -49,35 +147,59 @@ def step_bytes(st, N, H, W):
     else:
         Ho = Wo = 1
         pix_in = pix_out = N
+
     def nbytes(store, pixels, ch):
         return pixels * ch * 4 if store == abi.STORE_F32 else pixels * abi.words(store, ch) * 4
     return nbytes(st["x_store"], pix_in, cin) + nbytes(st["out_store"], pix_out, cout), Ho, Wo
 
 
-def cpu_baseline(cf, spec, seconds=12.0):
-    """Restated reference float path (not TensorFlow) on the host cores."""
-    base = importlib.import_module("oracle.cpu_baseline")
-    return base.run(cf, spec, seconds=seconds)
+def time_launch(torch, launch, reps=20, lead=4):
+    """Average duration of one launch, HIP events on the launching stream.  The first event is recorded
+    BEHIND a few queued launches, so the host's launch latency is not inside the measured interval:
+    (ev1 - ev0) / reps is the kernel's own duration, the figure rocprofv3's kernel trace reports."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    out = None
+    for _ in range(lead):
+        out = launch()
+    ev0.record()
+    for _ in range(reps):
+        out = launch()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps, out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="vgg64_full_qnn_w4a4", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=1, help="replay the forward from a hipGraph")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="batches kept in flight: graphs replayed round-robin on as many streams (measured: 1 -> 20.8 M, 2 -> 22.0 M, 3 -> 21.5 M img/s)")
-    ap.add_argument("--impl", default="auto", choices=["auto", "valu", "mfma"],
-                    help="conv kernel family (results are bit-identical)")
-    args = ap.parse_args()
+def layer_roof_ms(k):
+    """Roofline time of one launch: the slower of its HBM transfer and its matrix-pipe work."""
+    peak = MFMA_PEAK_TFLOPS["f32" if k["pipe"] == "f32" else "i8"] * 1e12
+    return max(k["bytes"] / (HBM_PEAK_GBS * 1e9), 2.0 * k["macs"] / peak) * 1e3
+
+
+def load_traffic(tag):
+    """HBM bytes per launch of kernel `tag` from the committed PMC passes (profiles/latest_traffic.json, written by
+    tools/summarize_profile.py; exact tag match).  rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE
+    counts 64 of every 128 fetched bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled."""
+    path = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    try:
+        ent = json.load(open(path)).get("by_tag", {}).get(tag)
+    except (OSError, ValueError):
+        return None, None
+    if not ent or "fetch_kb" not in ent or "write_kb" not in ent:
+        return None, None
+    return (2.0 * ent["fetch_kb"] + ent["write_kb"]) * 1024.0, ent.get("rocprof_kernel")
+
+
+def main_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
     backend = os.environ.get("QNN_DIST_BACKEND", "nccl")   # "gloo" only to rehearse N>1 on a 1-GPU box
     # QNN_BENCH_FORCE_DIST=1: run the N>1 code path (process group, logits all-gather) with a
     # single rank -- the only way to exercise the RCCL calls on a 1-GPU box
@@ -90,7 +212,8 @@ def main():
         json_fd = os.dup(1)
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())       # single-rank rehearsal only
         dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
@@ -99,14 +222,26 @@ def main():
     pkg = importlib.import_module(PKG)
     nets, engine, shard, abi = pkg.nets, pkg.engine, pkg.shard, pkg._abi
     abi.set_conv_impl({"auto": 0, "valu": 1, "mfma": 2}[args.impl])
+    if args.first_layer == "fixed":
+        abi.set_first_layer_mode(1)
     idx = WORKLOADS[args.workload]
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     fused = idx != 4
     model = engine.FusedModel(spec) if fused else engine.ResidualFusedModel(spec)
-    N = args.batch if fused or args.batch != BATCH else 64
-    # every rank owns a full batch (weak scaling: per-GPU work fixed)
-    x = torch.as_tensor(nets.synthetic_images(cf, N, nets.SEED_BASE + idx + 1000 * rank)).cuda()
+    batch = args.batch if fused or args.batch != BATCH else 64
+    if args.scaling == "weak":
+        # every rank owns a full batch: per-GPU work fixed as N grows
+        N = batch
+        x = torch.as_tensor(nets.synthetic_images(cf, N, nets.SEED_BASE + idx + 1000 * rank)).cuda()
+        global_batch = N * world
+    else:
+        # the global batch cut into contiguous equal shards (north_star: "inference batches shard embarrassingly")
+        xg = torch.as_tensor(nets.synthetic_images(cf, batch, nets.SEED_BASE + idx))
+        x = shard.shard_batch(xg, rank, world).cuda()
+        N = x.shape[0]
+        global_batch = batch
+        del xg
 
     def step():
         y = model(x)
@@ -120,51 +255,46 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    H, W = cf.dim, cf.dim
     per_kernel = []
-    cur = x
-    hh, ww = H, W
-    for st in (model.steps if fused else []):
-        nbytes, ho, wo = step_bytes(st, N, hh, ww)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps, lead = 20, 4
-        outs = None
+    if fused:
+        cur, hh, ww = x, cf.dim, cf.dim
+        for st in model.steps:
+            nbytes, ho, wo = step_bytes(abi, st, N, hh, ww)
 
-        def launch():
-            if st["kind"] == "conv":
-                o, _, _ = abi.conv2d(st["w"], cur, st["x_store"], st["x_bits"], N, hh, ww, st["inv"],
-                                     st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"])
-                return o
-            return abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
-                             st["fn"], st["act_bits"], st["out_store"])
+            def launch(st=st, cur=cur, hh=hh, ww=ww):
+                if st["kind"] == "conv":
+                    o, _, _ = abi.conv2d(st["w"], cur, st["x_store"], st["x_bits"], N, hh, ww, st["inv"],
+                                         st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"])
+                    return o
+                return abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
+                                 st["fn"], st["act_bits"], st["out_store"])
 
+            ms, outs = time_launch(torch, launch)
+            kh, kw, cin, cout = st["w"].shape
+            per_kernel.append(dict(kernel=abi.last_kernel(), ms=ms, bytes=nbytes, launches=1,
+                                   pipe="f32" if st["x_store"] == abi.STORE_F32 else "i8",
+                                   macs=N * (ho * wo * st["pool"] ** 2 if st["kind"] == "conv" else 1)
+                                   * kh * kw * cin * cout))
+            cur, hh, ww = outs, ho, wo
+    else:
+        # residual topology: ~130 launches per forward.  Every launch is captured with its operands and
+        # re-issued back to back for timing; launches of the same kernel on the same shape form one group
+        model.capture = []
+        model(x)
         torch.cuda.synchronize()
-        # the first event is recorded BEHIND a few queued launches, so the host's launch latency
-        # is not inside the measured interval: (ev1 - ev0) / reps is the kernel's own duration,
-        # the figure rocprofv3's kernel trace reports
-        for _ in range(lead):
-            outs = launch()
-        ev0.record()
-        for _ in range(reps):
-            outs = launch()
-        ev1.record()
-        torch.cuda.synchronize()
-        per_kernel.append(dict(kernel=abi.last_kernel(), ms=ev0.elapsed_time(ev1) / reps, bytes=nbytes,
-                               macs=N * (ho * wo * st["pool"] ** 2 if st["kind"] == "conv" else 1)
-                               * st["w"].shape[0] * st["w"].shape[1] * st["w"].shape[2] * st["w"].shape[3]))
-        cur, hh, ww = outs, ho, wo
-    if not fused:
-        # residual topology: ~200 launches per forward; report the whole forward against the
-        # float32-surface (M0) bytes of SURVEY.md 8d instead of a single kernel
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(3):
-            model(x)
-        ev1.record()
-        torch.cuda.synchronize()
-        per_kernel.append(dict(kernel="residual_forward(all launches)", ms=ev0.elapsed_time(ev1) / 3,
-                               bytes=30307912 * N, macs=6855277184 * N))   # M1 bytes/img, SURVEY.md 8d
-    dom = max(range(len(per_kernel)), key=lambda i: per_kernel[i]["ms"])
+        groups = {}
+        for c in model.capture:
+            ms, _ = time_launch(torch, c["launch"], reps=8, lead=2)
+            g = groups.setdefault((c["kernel"], c["shape"]), dict(kernel=c["kernel"], shape=c["shape"], ms_total=0.0,
+                                                                  launches=0, bytes=c["bytes"], macs=c["macs"],
+                                                                  pipe=c["pipe"]))
+            g["ms_total"] += ms
+            g["launches"] += 1
+        model.capture = None
+        for g in groups.values():
+            per_kernel.append(dict(kernel=g["kernel"], shape=g["shape"], ms=g["ms_total"] / g["launches"],
+                                   launches=g["launches"], bytes=g["bytes"], macs=g["macs"], pipe=g["pipe"]))
+    dom = max(range(len(per_kernel)), key=lambda i: per_kernel[i]["ms"] * per_kernel[i]["launches"])
 
     # ---- hipGraph of the model forward (launch-bound inner loop); the logits all-gather stays
     # outside the graph and runs on RCCL's own stream, overlapped with the next batch.
@@ -189,7 +319,6 @@ def main():
             print("hipGraph capture failed (%s); running eagerly" % exc, file=sys.stderr)
             lanes = []
     graph = lanes[0]["graph"] if lanes else None
-    y_static = lanes[0]["y"] if lanes else None
     torch.cuda.synchronize()
 
     # logits exchange (N > 1): the (B, classes) float32 block of this rank is copied to a staging
@@ -234,91 +363,103 @@ def main():
                         ln["works"][k].wait()
                         ln["works"][k] = None
 
+    def timed_region():
+        """EXACTLY --steps steps between two (barrier + synchronize) brackets; MAX over ranks."""
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        drain()                                        # every gather of the timed steps has completed ...
+        torch.cuda.synchronize()                       # ... before the clock stops
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         run_step()
     drain()
-    # dominant-kernel events inside the timed region only make sense eagerly; with a
-    # graph the per-kernel figure above (same launches, same stream) is reported
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    drain()                                        # every gather of the timed steps has completed ...
-    torch.cuda.synchronize()                       # ... before the clock stops
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    regions = []
+    # the number of regions must be the same on every rank: rank 0 decides, from max-over-ranks times
+    while True:
+        regions.append(timed_region())
+        more = len(regions) < args.repeats or (sum(regions) < 0.3 and len(regions) < 50)
+        if world > 1:
+            flag = torch.tensor([1 if more else 0], dtype=torch.int32, device="cpu" if backend == "gloo" else "cuda")
+            dist.broadcast(flag, src=0)
+            more = bool(flag.item())
+        if not more:
+            break
+    dt = float(np.median(regions))
+
     if pipelined and rank == 0:
         # the gathered block must hold this rank's logits at its own offset
         ln = lanes[(counter[0] - 1) % len(lanes)]
         nloc = ln["y"].shape[0]
         torch.testing.assert_close(ln["gathered"][(ln["count"] - 1) & 1][rank * nloc:(rank + 1) * nloc],
                                    ln["y"], rtol=0, atol=0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * N * args.steps / dt
+        value = global_batch * args.steps / dt
         d = per_kernel[dom]
         hbm_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                prefix = ("k_conv_first" if d["kernel"].startswith("mfma_f32_first") else
-                          "k_conv_mfma" if d["kernel"].startswith("mfma_i") else
-                          "k_conv_ps" if d["kernel"].startswith("ps_") else
-                          "k_dense_packed" if d["kernel"].startswith("dense_") else "k_conv_generic")
-                cands = [v for k, v in tj.items() if k.startswith(prefix)]
-                ent = cands[0] if len(cands) == 1 else {}
-                if ent:
-                    # rocprofv3 FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE counts 64 of every
-                    # 128 fetched bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled
-                    traffic = (2.0 * ent.get("fetch_kb", 0.0) + ent.get("write_kb", 0.0)) * 1024.0
-            except Exception:
-                traffic = None
-        if d["kernel"].startswith("mfma_"):
-            kind = "f32" if d["kernel"].startswith("mfma_f32") else "i8"
+        traffic, rocprof_name = load_traffic(d["kernel"])
+        common = {"kernel": d["kernel"], "rocprof_kernel": rocprof_name, "layer_index": dom,
+                  "launches_per_step": d["launches"], "avg_launch_ms": d["ms"],
+                  "algorithmic_bytes_per_launch": d["bytes"], "traffic": traffic}
+        if d["kernel"].startswith("mfma_") and 2.0 * d["macs"] / (MFMA_PEAK_TFLOPS["f32" if d["pipe"] == "f32" else "i8"] * 1e12) \
+                >= d["bytes"] / (HBM_PEAK_GBS * 1e9):
+            kind = "f32" if d["pipe"] == "f32" else "i8"
             achieved = 2.0 * d["macs"] / (d["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": d["kernel"], "layer_index": dom, "achieved": achieved,
-                    "peak": MFMA_PEAK_TFLOPS[kind], "unit": "TFLOP/s",
-                    "frac": achieved / MFMA_PEAK_TFLOPS[kind], "traffic": traffic,
-                    "mfma_dtype": kind, "algorithmic_flops_per_launch": 2.0 * d["macs"],
-                    "algorithmic_bytes_per_launch": d["bytes"], "avg_launch_ms": d["ms"],
-                    "hbm_GBps": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS}
+            roof = dict(common, bound="mfma", achieved=achieved, peak=MFMA_PEAK_TFLOPS[kind], unit="TFLOP/s",
+                        frac=achieved / MFMA_PEAK_TFLOPS[kind], mfma_dtype=kind,
+                        algorithmic_flops_per_launch=2.0 * d["macs"], hbm_GBps=hbm_gbs,
+                        hbm_frac=hbm_gbs / HBM_PEAK_GBS)
         else:
-            roof = {"bound": "hbm", "kernel": d["kernel"], "layer_index": dom, "achieved": hbm_gbs,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": d["bytes"], "avg_launch_ms": d["ms"],
-                    "note": "VALU-bound packed kernel; see kernels[].TMACps and DESIGN.md"}
-        m0_bytes = {1: 442408, 2: 442408, 3: 7237672, 4: 238248232}[idx]     # SURVEY.md 8d, float32-surface traffic per image
+            roof = dict(common, bound="hbm", achieved=hbm_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=hbm_gbs / HBM_PEAK_GBS)
+        # one end-to-end fraction: the sum of every launch's own roofline time over the measured step
+        roof_ms = sum(layer_roof_ms(k) * k["launches"] for k in per_kernel)
+        per_gpu_step_ms = ms_per_step
+        roof["pipeline_roof_ms"] = roof_ms
+        roof["pipeline_frac"] = roof_ms / per_gpu_step_ms
         out = {
             "metric": "images/sec @ batch 4096, CIFAR-10 VGG full-qnn 4/4; % HBM roofline",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {1: "u1", 2: "int4", 3: "int8", 4: "int4"}[idx],
-            "data": "synthetic",
-            "config": {"workload": args.workload, "batch_per_gpu": N, "global_batch": N * world,
-                       "traffic_model": "M1 (packed inter-layer tensors)", "engine": "FusedModel" if fused else "ResidualFusedModel",
-                       "conv_impl": args.impl, "hipgraph": graph is not None, "batches_in_flight": len(lanes) if lanes else 1,
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": {1: "u1", 2: "int4", 3: "int8", 4: "int4"}[idx], "data": "synthetic",
+            "config": {"workload": args.workload, "batch_per_gpu": N, "global_batch": global_batch,
+                       "traffic_model": "M1 (packed inter-layer tensors)",
+                       "engine": "FusedModel" if fused else "ResidualFusedModel",
+                       "conv_impl": args.impl, "first_layer": args.first_layer,
+                       "hipgraph": graph is not None, "batches_in_flight": len(lanes) if lanes else 1,
                        "parallelism": "dp%d" % world,
-                       # the metric's "% HBM roofline" in BASELINE.md's sense: float32-surface (M0) bytes
-                       # per image x images/s over 8 TB/s (the fused engine does not move those bytes)
-                       "pct_of_m0_hbm_roofline": 100.0 * value / world * m0_bytes / (HBM_PEAK_GBS * 1e9)},
+                       "dist_backend": backend if use_dist else None,
+                       "rccl_world_size": world if (use_dist and backend == "nccl") else (1 if not use_dist else 0),
+                       "timed_regions": len(regions),
+                       "region_ms_min_median_max": [round(min(regions) * 1e3, 4), round(dt * 1e3, 4),
+                                                    round(max(regions) * 1e3, 4)],
+                       # the metric's "% HBM roofline" for what the fused engine really moves: M1 bytes per
+                       # image x images/s per GPU over 8 TB/s (the path is compute-bound, see roofline)
+                       "m1_hbm_frac": value / world * M1_BYTES[idx] / (HBM_PEAK_GBS * 1e9)},
             "roofline": roof,
-            "kernels": [{"kernel": k["kernel"], "ms": round(k["ms"], 5),
+            "kernels": [{"kernel": k["kernel"], "launches": k["launches"], "ms": round(k["ms"], 5),
                          "GBps": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 2),
-                         "TMACps": round(k["macs"] / (k["ms"] * 1e-3) / 1e12, 3)} for k in per_kernel],
+                         "TMACps": round(k["macs"] / (k["ms"] * 1e-3) / 1e12, 3),
+                         "roof_ms": round(layer_roof_ms(k), 5),
+                         **({"shape": list(k["shape"])} if "shape" in k else {})} for k in per_kernel],
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(cf, spec)
+                out["cpu_baseline"] = importlib.import_module("oracle.cpu_baseline").run(cf, spec, seconds=12.0)
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"error": str(exc)}
         line = json.dumps(out) + "\n"
@@ -331,5 +472,16 @@ def main():
         dist.destroy_process_group()
 
 
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    main_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

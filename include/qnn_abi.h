@@ -116,6 +116,12 @@ int qnn_quantized_tanh_f32(const float* x, float* y, size_t n, int nb, void* str
  * mean(|clip(x)|) first: `workspace16` is 16 bytes of caller-owned device memory
  * for the running sum.  Memset + two kernels on `stream`. */
 int qnn_ternary_tanh_f32(const float* x, float* y, size_t n, void* workspace16, void* stream);
+/* The same op in its two halves, for a batch tensor that is sharded over processes (the mean of
+ * ternary_ops.py:23 is over the WHOLE tensor): abs_sum leaves {sum |clip(x,-1,1)|, n} as two doubles
+ * in `workspace16`; the caller all-reduces (sums) those 16 bytes across the shards; apply thresholds
+ * at 0.7 * workspace16[0] / workspace16[1]. */
+int qnn_ternary_abs_sum_f32(const float* x, size_t n, void* workspace16, void* stream);
+int qnn_ternary_apply_f32(const float* x, float* y, size_t n, const void* workspace16, void* stream);
 
 /* ---- pack / unpack between float32 NHWC and packed storage --------------- */
 /* bytes of a packed tensor of `pixels` pixels x `channels` channels */

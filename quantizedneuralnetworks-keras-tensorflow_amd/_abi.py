@@ -20,6 +20,7 @@ FN_NONE, FN_BINARY_TANH, FN_QUANTIZED_TANH, FN_TERNARY_TANH, FN_GRID = 0, 1, 2, 
 EXPORTS = [
     "qnn_version", "qnn_last_error", "qnn_last_kernel", "qnn_set_conv_impl",
     "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
+    "qnn_ternary_abs_sum_f32", "qnn_ternary_apply_f32",
     "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32",
     "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant",
     "qnn_conv2d_forward", "qnn_dense_forward", "qnn_conv2d_forward_f32in", "qnn_conv2d_workspace_bytes",
@@ -36,6 +37,11 @@ class Epilogue(ctypes.Structure):
 
 class QnnError(RuntimeError):
     pass
+
+
+class NotFusable(QnnError):
+    """A net spec that engine.FusedModel cannot express as one packed chain (the caller picks another
+    engine).  Every other failure -- prepack, out of memory, a planner bug -- stays a plain QnnError."""
 
 
 _lib = None
@@ -55,6 +61,10 @@ def load():
         raise QnnError(
             "libqnn_hip.so is not built (%s). Run `python -c \"import __graft_entry__ as g; "
             "g.build()\"` (needs hipcc). There is no CPU fallback." % path)
+    if _build.built_hash() != _build.source_hash() and os.environ.get("QNN_ALLOW_STALE_LIB") != "1":
+        raise QnnError(
+            "libqnn_hip.so was built from other sources than the ones in csrc/ (stamp %s, sources %s). Rebuild: "
+            "`python -c \"import __graft_entry__ as g; g.build()\"`." % (_build.built_hash(), _build.source_hash()))
     lib = ctypes.CDLL(path)
     vp, ci, sz, fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
     lib.qnn_version.restype = ci
@@ -64,6 +74,8 @@ def load():
     lib.qnn_binary_tanh_f32.argtypes = [vp, vp, sz, vp]
     lib.qnn_quantized_tanh_f32.argtypes = [vp, vp, sz, ci, vp]
     lib.qnn_ternary_tanh_f32.argtypes = [vp, vp, sz, vp, vp]
+    lib.qnn_ternary_abs_sum_f32.argtypes = [vp, sz, vp, vp]
+    lib.qnn_ternary_apply_f32.argtypes = [vp, vp, sz, vp, vp]
     lib.qnn_packed_bytes.argtypes = [ci, sz, ci]
     lib.qnn_packed_bytes.restype = sz
     lib.qnn_pack_f32.argtypes = [vp, vp, sz, ci, ci, ci, ci, vp]

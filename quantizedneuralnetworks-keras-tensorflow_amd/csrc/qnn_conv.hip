@@ -242,56 +242,41 @@ __global__ __launch_bounds__(kBlock) void k_conv_generic(ConvGeom g, EpiArgs e, 
 
 // ---------------------------------------------------------------------------
 // dense layer on float32 features (the classifier behind a global average pool,
-// models/resnet.py:138-142): the same ascending-k fmaf chain as conv_point
+// models/resnet.py:138-142; the 'qnn' / 'bnn' / 'tnn' networks whose activations are
+// LeakyReLU floats).  K.dot is a float32 matmul whose summation order TensorFlow does
+// not specify; this kernel returns the CORRECTLY ROUNDED dot product: every float32
+// product is exact in float64, the 64 lanes accumulate strided partial sums in float64
+// (relative error ~1e-16), one butterfly reduction, one rounding to float32.  That is
+// the oracle's `dot` (float64 accumulate, one rounding) and is within half an ulp of
+// the exact value -- a float32 fmaf chain over K = 1024 unit-scale terms is already
+// 1.8e-5 away from it (measured), outside the 1e-5 band of the north star.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_dense_f32in(EpiArgs e, int N, int cin, int cout,
                                                     const float* __restrict__ x,
                                                     const float* __restrict__ wq,
                                                     float* __restrict__ y) {
-    // One wave per (row, output).  The chain is sequential by definition (ascending k, one
-    // rounding per fmaf), so the wave only parallelises the operand traffic: 64 lanes fetch a
-    // 256-element chunk of both vectors with coalesced 16-byte loads into LDS, then every lane
-    // runs the same chain on LDS broadcast reads (a thread-per-output loop pays one global
-    // round trip per four elements: 130 us for the 3136 -> 10 ResNet classifier, here ~10 us).
-    constexpr int CH = 256;
-    __shared__ __attribute__((aligned(16))) float xs[2][CH], ws[2][CH];
     const int t = blockIdx.x;
     const int n = t / cout, c = t - n * cout;
     const int lane = threadIdx.x;
     const float* a = x + (size_t)n * cin;
     const float* w = wq + (size_t)c * cin;
-    const bool vec = (cin & 3) == 0;
-    auto fetch = [&](int k0, int buf) {
-        const int k = k0 + 4 * lane;
-        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
-        if (vec && k + 3 < cin) {
-            av = *reinterpret_cast<const float4*>(a + k);
-            wv = *reinterpret_cast<const float4*>(w + k);
-        } else {
-            if (k < cin) { av.x = a[k]; wv.x = w[k]; }
-            if (k + 1 < cin) { av.y = a[k + 1]; wv.y = w[k + 1]; }
-            if (k + 2 < cin) { av.z = a[k + 2]; wv.z = w[k + 2]; }
-            if (k + 3 < cin) { av.w = a[k + 3]; wv.w = w[k + 3]; }
+    double acc0 = 0.0, acc1 = 0.0;
+    if ((cin & 3) == 0) {
+        for (int k = 4 * lane; k < cin; k += 256) {        // coalesced 16-byte loads of both vectors
+            const float4 av = *reinterpret_cast<const float4*>(a + k);
+            const float4 wv = *reinterpret_cast<const float4*>(w + k);
+            acc0 += (double)av.x * (double)wv.x;
+            acc1 += (double)av.y * (double)wv.y;
+            acc0 += (double)av.z * (double)wv.z;
+            acc1 += (double)av.w * (double)wv.w;
         }
-        *reinterpret_cast<float4*>(&xs[buf][4 * lane]) = av;
-        *reinterpret_cast<float4*>(&ws[buf][4 * lane]) = wv;
-    };
-    float acc = 0.0f;
-    fetch(0, 0);
-    int buf = 0;
-    for (int k0 = 0; k0 < cin; k0 += CH, buf ^= 1) {
-        __syncthreads();                               // chunk k0 is in LDS (single wave: cheap)
-        if (k0 + CH < cin) fetch(k0 + CH, buf ^ 1);    // next chunk in flight under the chain
-        const int cnt = min(CH, cin - k0);
-        int k = 0;
-        for (; k + 3 < cnt; k += 4) {
-            const float4 av = *reinterpret_cast<const float4*>(&xs[buf][k]);
-            const float4 wv = *reinterpret_cast<const float4*>(&ws[buf][k]);
-            acc = fmaf(av.x, wv.x, acc); acc = fmaf(av.y, wv.y, acc);
-            acc = fmaf(av.z, wv.z, acc); acc = fmaf(av.w, wv.w, acc);
-        }
-        for (; k < cnt; ++k) acc = fmaf(xs[buf][k], ws[buf][k], acc);
+    } else {
+        for (int k = lane; k < cin; k += 64) acc0 += (double)a[k] * (double)w[k];
     }
+    double sum = acc0 + acc1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float acc = (float)sum;
     if (lane == 0) {
         float v = qnn_epi_value(acc, c, e);
         if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void k_tern_sum(const float* __restrict__ x
 __global__ __launch_bounds__(kBlock) void k_tern_apply(const float* __restrict__ x,
                                                        float* __restrict__ y, size_t n,
                                                        const double* __restrict__ sum) {
-    const float mean_abs = (float)(*sum / (double)n);
+    const float mean_abs = (float)(sum[0] / sum[1]);     // (sum |clip(x)|, element count): all-reduced when sharded
     const float cutoff = __fmul_rn(0.7f, mean_abs);
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -247,18 +247,34 @@ extern "C" int qnn_quantized_tanh_f32(const float* x, float* y, size_t n, int nb
     return QNN_OK;
 }
 
+extern "C" int qnn_ternary_abs_sum_f32(const float* x, size_t n, void* workspace16, void* stream) {
+    QNN_REQUIRE(x && workspace16, QNN_EINVAL, "qnn_ternary_abs_sum_f32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const double init[2] = {0.0, (double)n};
+    QNN_HIP(hipMemcpyAsync(workspace16, init, 16, hipMemcpyHostToDevice, s));
+    if (n == 0) return QNN_OK;
+    const int g = grid_for(n) < 1024 ? grid_for(n) : 1024;
+    hipLaunchKernelGGL(k_tern_sum, dim3(g), dim3(kBlock), 0, s, x, n, (double*)workspace16);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+extern "C" int qnn_ternary_apply_f32(const float* x, float* y, size_t n, const void* workspace16, void* stream) {
+    QNN_REQUIRE(x && y && workspace16, QNN_EINVAL, "qnn_ternary_apply_f32: null pointer");
+    if (n == 0) return QNN_OK;
+    hipLaunchKernelGGL(k_tern_apply, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, x, y, n,
+                       (const double*)workspace16);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
 extern "C" int qnn_ternary_tanh_f32(const float* x, float* y, size_t n, void* workspace16,
                                     void* stream) {
     QNN_REQUIRE(x && y && workspace16, QNN_EINVAL, "qnn_ternary_tanh_f32: null pointer");
     if (n == 0) return QNN_OK;
-    hipStream_t s = (hipStream_t)stream;
-    QNN_HIP(hipMemsetAsync(workspace16, 0, 16, s));
-    const int g = grid_for(n) < 1024 ? grid_for(n) : 1024;
-    hipLaunchKernelGGL(k_tern_sum, dim3(g), dim3(kBlock), 0, s, x, n, (double*)workspace16);
-    hipLaunchKernelGGL(k_tern_apply, dim3(grid_for(n)), dim3(kBlock), 0, s, x, y, n,
-                       (const double*)workspace16);
-    QNN_HIP(hipGetLastError());
-    return QNN_OK;
+    int rc = qnn_ternary_abs_sum_f32(x, n, workspace16, stream);
+    if (rc != QNN_OK) return rc;
+    return qnn_ternary_apply_f32(x, y, n, workspace16, stream);
 }
 
 extern "C" size_t qnn_packed_bytes(int store, size_t pixels, int channels) {

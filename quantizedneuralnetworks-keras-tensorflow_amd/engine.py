@@ -108,14 +108,14 @@ class FusedModel:
         self._keep = []
         groups = self._group(spec)
         if groups is None:
-            raise _abi.QnnError("FusedModel: spec is not a fusable chain; use GraphModel")
+            raise _abi.NotFusable("FusedModel: spec is not a fusable chain; use GraphModel")
         x_store, x_bits = _abi.STORE_F32, 0
         for gi, g in enumerate(groups):
             op = g["op"]
             nxt = groups[gi + 1]["op"] if gi + 1 < len(groups) else None
             store_in = x_store
             if store_in != _abi.STORE_F32 and _wstore(op) is None:
-                raise _abi.QnnError("FusedModel: float layer after a packed tensor")
+                raise _abi.NotFusable("FusedModel: float layer after a packed tensor")
             w = _prepack(op, store_in, self.device, stride=g["stride"], same_pad=g["same"])
             inv = shift = None
             if g["bn"] is not None:
@@ -125,18 +125,28 @@ class FusedModel:
                 self._keep += [inv, shift]
             ac = _act_code(g["act"])
             if g["act"] is not None and ac is None:
-                raise _abi.QnnError("FusedModel: activation %r cannot be fused" % g["act"]["fn"])
+                raise _abi.NotFusable("FusedModel: activation %r cannot be fused" % g["act"]["fn"])
             if ac is None:
                 fn, bits, out_store = _abi.FN_NONE, 0, _abi.STORE_F32
                 if nxt is not None:
-                    raise _abi.QnnError("FusedModel: layer without a low-bit activation mid-chain")
+                    raise _abi.NotFusable("FusedModel: layer without a low-bit activation mid-chain")
             else:
                 fn, bits = ac
                 out_store = _join_store(bits, _wstore(nxt)) if nxt is not None else _abi.STORE_F32
                 if out_store is None:
-                    raise _abi.QnnError("FusedModel: float layer after a low-bit activation")
+                    raise _abi.NotFusable("FusedModel: float layer after a low-bit activation")
                 if out_store == _abi.STORE_BIN and _matrix_pipe_1bit(nxt):
                     out_store = _abi.STORE_I4
+                if g["kind"] == "conv" and nxt is not None and nxt["op"] == "dense":
+                    # Flatten of a packed tensor is a no-op only when every pixel's channels fill whole
+                    # words: the conv pads each pixel to a word boundary, the dense weights are packed as
+                    # one contiguous K = H*W*C vector.  Widen the storage until the channels divide.
+                    cout = op["kernel"].shape[3]
+                    while cout % _abi.per_word(out_store) != 0 and out_store < _abi.STORE_I8:
+                        out_store = {_abi.STORE_BIN: _abi.STORE_I4, _abi.STORE_I4: _abi.STORE_I8}[out_store]
+                    if cout % _abi.per_word(out_store) != 0:
+                        raise _abi.NotFusable("FusedModel: %d channels in front of Flatten do not fill whole "
+                                              "packed words" % cout)
             self.steps.append(dict(kind=g["kind"], w=w, x_store=x_store, x_bits=x_bits, inv=inv,
                                    shift=shift, fn=fn, act_bits=bits if fn == _abi.FN_QUANTIZED_TANH else 0,
                                    pool=g["pool"], out_store=out_store, softmax=g.get("softmax", False)))
@@ -421,6 +431,7 @@ class ResidualFusedModel:
                 inv, shift = bn_constants(op)
                 self._bn[i] = (torch.as_tensor(inv).to(self.device), torch.as_tensor(shift).to(self.device))
         self.kernel_log = None
+        self.capture = None
 
     # ---- helpers -----------------------------------------------------------------
     def _weights(self, i, store):
@@ -482,14 +493,32 @@ class ResidualFusedModel:
             if isinstance(src, _Packed):
                 N, H, W, C = src.shape
                 w = self._weights(ci, src.store)
-                y, Ho, Wo = _abi.conv2d(w, src.t, src.store, src.bits, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
+                xin, xs, xb = src.t, src.store, src.bits
             else:
                 N, H, W, C = src.shape
                 w = self._weights(ci, _abi.STORE_F32)
-                y, Ho, Wo = _abi.conv2d(w, src.contiguous(), _abi.STORE_F32, 0, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
+                xin, xs, xb = src.contiguous(), _abi.STORE_F32, 0
+
+            def launch():
+                return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
+
+            y, Ho, Wo = launch()
             if self.kernel_log is not None:
                 self.kernel_log.append(_abi.last_kernel())
             cout = op["kernel"].shape[3]
+            if self.capture is not None:
+                # bench.py re-issues every launch of one forward for per-kernel timing: the closure keeps the
+                # operands alive; bytes = tensors as stored (input + output + shortcut), SURVEY.md 8d model M1
+                def nbytes(store, pixels, ch):
+                    return pixels * ch * 4 if store == _abi.STORE_F32 else pixels * _abi.words(store, ch) * 4
+                kh, kw = op["kernel"].shape[:2]
+                b = nbytes(xs, N * H * W, C) + nbytes(out_store, N * Ho * Wo, cout)
+                if res is not None:
+                    b += nbytes(rkw["res_store"], N * Ho * Wo, cout)
+                self.capture.append(dict(kernel=_abi.last_kernel(), launch=lambda: launch()[0],
+                                         shape=(N, H, W, C, cout, kh, tuple(op.get("strides", (1, 1)))[0]),
+                                         bytes=b, macs=N * Ho * Wo * kh * kw * C * cout,
+                                         pipe="f32" if xs == _abi.STORE_F32 else "i8"))
             if out_store == _abi.STORE_F32:
                 return y
             return _Packed(y, out_store, bits, (N, Ho, Wo, cout))

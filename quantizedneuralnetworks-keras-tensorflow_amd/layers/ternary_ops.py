@@ -9,13 +9,23 @@ import torch
 from .. import _abi
 
 
-def ternary_tanh(x):
-    """ternary_ops.py:52-54: ternarize(clip(x,-1,1))."""
+def ternary_tanh(x, group=None):
+    """ternary_ops.py:52-54: ternarize(clip(x,-1,1)).
+
+    The cutoff is 0.7 * mean|clip(x)| over the WHOLE batch tensor (ternary_ops.py:23).  When the batch is
+    sharded over processes (`shard.sharded(...)` is active, or `group` is given) the two partial sums
+    {sum|clip(x)|, count} are all-reduced between the reduction kernel and the threshold kernel, so every
+    shard thresholds at the global mean: the result equals the single-process one."""
+    from .. import shard
     x = _abi.require_cuda(x, "ternary_tanh")
     y = torch.empty_like(x)
     ws = torch.empty(2, dtype=torch.float64, device=x.device)
-    _abi.check(_abi.load().qnn_ternary_tanh_f32(_abi.ptr(x), _abi.ptr(y), x.numel(), _abi.ptr(ws),
-                                                _abi.stream_ptr()), "ternary_tanh")
+    lib = _abi.load()
+    _abi.check(lib.qnn_ternary_abs_sum_f32(_abi.ptr(x), x.numel(), _abi.ptr(ws), _abi.stream_ptr()),
+               "ternary_tanh")
+    shard.allreduce_sum_count(ws, group)
+    _abi.check(lib.qnn_ternary_apply_f32(_abi.ptr(x), _abi.ptr(y), x.numel(), _abi.ptr(ws), _abi.stream_ptr()),
+               "ternary_tanh")
     return y
 
 

@@ -273,11 +273,11 @@ class Model:
     set of weights, executing on the fused GPU engines."""
 
     def __init__(self, cf, spec, device="cuda"):
-        from . import engine
+        from . import engine, _abi
         self.cf, self.spec = cf, spec
         try:
             self.engine = engine.FusedModel(spec, device)          # chains (VGG)
-        except Exception:
+        except _abi.NotFusable:
             self.engine = engine.ResidualFusedModel(spec, device)   # residual / non-fusable topologies
         self.layers = [op for op in spec if op["op"] in ("conv", "dense")]
 

@@ -44,8 +44,40 @@ def gather_logits(local, total=None, group=None):
     return out if total is None else out[:total]
 
 
+_ACTIVE = []          # stack of process groups inside `with sharded(group):`
+
+
+class sharded:
+    """Context in which batch tensors are SHARDS of a global batch: ops that reduce over the whole batch
+    tensor (ternary_tanh, ternary_ops.py:23) all-reduce their partial sums over `group`."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __enter__(self):
+        _ACTIVE.append(self.group if self.group is not None else (dist.group.WORLD if dist.is_initialized() else None))
+        return self
+
+    def __exit__(self, *exc):
+        _ACTIVE.pop()
+        return False
+
+
+def allreduce_sum_count(ws, group=None):
+    """Sum the {sum|clip(x)|, count} pair of ternary_tanh over the shards (in place).  No-op outside a sharded
+    context / for a single process."""
+    if group is None and _ACTIVE:
+        group = _ACTIVE[-1]
+    elif group is None:
+        return ws
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(ws, group=group)
+    return ws
+
+
 def allreduce_mean_abs(x, group=None):
-    """Global mean(|clip(x,-1,1)|) of a batch-sharded tensor (for ternary_tanh)."""
+    """Global mean(|clip(x,-1,1)|) of a batch-sharded tensor: the statistic ternary_tanh thresholds at,
+    computed with torch ops (used by the CPU tests; the GPU path is ternary_ops.ternary_tanh)."""
     s = torch.stack([x.clamp(-1, 1).abs().double().sum(),
                      torch.tensor(float(x.numel()), dtype=torch.float64, device=x.device)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -54,7 +86,10 @@ def allreduce_mean_abs(x, group=None):
 
 
 def sharded_forward(model, x_global, rank, world, group=None):
-    """forward(shard) on every rank + all-gather of the logits."""
+    """forward(shard) on every rank + all-gather of the logits.  Runs inside `sharded(group)`, so a
+    full-tnn network thresholds its ternary activations at the global batch mean."""
     total = x_global.shape[0]
-    local = model(shard_batch(x_global, rank, world))
+    lo, hi, per = shard_bounds(total, rank, world)
+    with sharded(group):
+        local = model(shard_batch(x_global, rank, world))
     return gather_logits(local, total, group)

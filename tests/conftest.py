@@ -30,12 +30,13 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built_library():
-    """The C-ABI library is a build artefact (git-ignored): build it once if this checkout has none
-    (hipcc cross-compiles gfx950 without a GPU, ~1.5 min).  The product path itself never builds or
+    """The C-ABI library is a build artefact (git-ignored): build it once if this checkout has none or its
+    stamp does not match the sources (content hash, not mtime; hipcc cross-compiles gfx950 without a GPU, ~1 min).  The product path itself never builds or
     falls back: a missing library raises QnnError."""
+    import importlib
     import shutil
-    so = os.path.join(ROOT, "quantizedneuralnetworks-keras-tensorflow_amd", "csrc", "libqnn_hip.so")
-    if not os.path.exists(so) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+    build = importlib.import_module("quantizedneuralnetworks-keras-tensorflow_amd._build")
+    if build.needs_build() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         import __graft_entry__
         __graft_entry__.build()
     yield

@@ -31,6 +31,13 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
+def within(got, want, mult=1.0):
+    """|got - want| <= mult * 1e-5 * max(1, |want|); the failure message carries the measured ratio."""
+    r = float((np.abs(got.astype(np.float64) - want) / (1e-5 * np.maximum(1.0, np.abs(want)))).max())
+    assert r <= mult, "max |d| / (1e-5*max(1,|y|)) = %.3g > %g" % (r, mult)
+    return r
+
+
 def edge_values():
     e = [0.0, -0.0, 2.0 ** -24, 2.0 ** -23, -2.0 ** -24, 1e-9, -1e-9, 1e-45, 0.5, -0.5, 1.0, -1.0,
          0.0625, 0.1875, 0.3125, 0.4375, 0.9375, 0.96875, -0.0625, -0.1875, -0.3125, -0.9375, -1.2, 1.2,
@@ -393,7 +400,7 @@ def test_dense_layer(kind, nb, in_act):
     else:
         got = host(layer(dev(x)))
         want = O.run_spec([op], x)
-        assert np.all(np.abs(got.astype(np.float64) - want) <= 1e-5 * np.maximum(1, np.abs(want)) * 4)
+        within(got, want)
 
 
 def test_layer_classes_on_trained_weights():
@@ -425,7 +432,7 @@ def test_layer_classes_on_trained_weights():
             np.testing.assert_array_equal(got_float, want)
             # faithful replay of the lr-multiplier trick stays within the documented band
             fa = O.run_spec([dict(op, klm=np.float32(lm["klm"]))], x, mode="faithful")
-            assert np.all(np.abs(fa.astype(np.float64) - want) <= 1e-5 * np.maximum(1, np.abs(want)) * 8)
+            within(fa, want)
 
 
 # ---------------------------------------------------------------------------
@@ -445,10 +452,46 @@ def test_vgg_configs_end_to_end(idx, impl):
     layer = host(engine.LayerModel(spec)(dev(x)))
     np.testing.assert_array_equal(layer, want)
     ideal = O.run_spec(spec, x)
-    # vs the ideal float conv: identical unless a first-layer value sits within an
-    # ulp of a quantisation threshold (then one code flips); report, do not hide
-    frac = float(np.mean(got != ideal))
-    assert frac <= 0.2, frac
+    # vs the ideal (float64-accumulated) first-layer conv: identical unless a first-layer value sits within
+    # an ulp of a quantisation threshold, where one activation code flips and the logits of that image move.
+    # Measured on these seeds: no image of any of the three configurations differs.
+    rows = int(np.any(got != ideal, axis=1).sum())
+    assert rows == 0, rows
+
+
+@pytest.mark.parametrize("nt,wb,ab,nfc", [("full-bnn", 1, 1, 16), ("full-bnn", 1, 1, 48), ("full-qnn", 4, 4, 20),
+                                          ("full-qnn", 4, 4, 12), ("full-qnn", 8, 8, 6), ("full-qnn", 4, 4, 7)])
+def test_flatten_of_channels_that_do_not_fill_packed_words(nt, wb, ab, nfc):
+    """The conv in front of Flatten pads every pixel to a word boundary; the dense weights are packed as one
+    contiguous K = H*W*C vector.  FusedModel widens the storage until the channels fill whole words, or
+    declares the chain not fusable (nets.Model then takes the residual engine); never silently wrong."""
+    cf = nets.Config(network_type=nt, wbits=wb, abits=ab, architecture="VGG", nfa=32, nfb=32, nfc=nfc)
+    spec = nets.build_spec(cf, 5)
+    x = nets.synthetic_images(cf, 3, 5)
+    want = O.run_spec(spec, x, float_conv="device")
+    try:
+        fused = engine.FusedModel(spec)
+    except _abi.NotFusable:
+        assert nfc % 4 != 0                       # no packed storage whose words the channels fill
+        fused = None
+    if fused is not None:
+        last_conv = [st for st in fused.steps if st["kind"] == "conv"][-1]
+        assert nfc % _abi.per_word(last_conv["out_store"]) == 0
+        np.testing.assert_array_equal(host(fused(dev(x))), want)
+    model = nets.Model(cf, spec)
+    assert type(model.engine).__name__ == ("FusedModel" if fused is not None else "ResidualFusedModel")
+    np.testing.assert_array_equal(model.predict(x), want)
+
+
+def test_model_does_not_mask_real_errors_as_not_fusable(monkeypatch):
+    cf = nets.baseline_config(2)
+    spec = nets.build_spec(cf, 1)
+
+    def boom(*a, **k):
+        raise _abi.QnnError("prepack failed")
+    monkeypatch.setattr(engine, "_prepack", boom)
+    with pytest.raises(_abi.QnnError, match="prepack failed"):
+        nets.Model(cf, spec)
 
 
 def test_one_bit_layers_on_the_matrix_pipe():
@@ -585,6 +628,25 @@ def test_residual_fused_model_at_imagenet_geometry():
         assert k in m.kernel_log, m.kernel_log
 
 
+def test_config5_imagenet224_resnet_nres10_at_spec():
+    """BASELINE config 5 as stated: ImageNet-224 ResNet, nres = 10 (63 convolutions, 62-layer deep chain of
+    fused residual launches), full-qnn 4/4 -- logits of one image bit for bit against the oracle."""
+    cf = nets.baseline_config(4)
+    assert (cf.nres, cf.dim, cf.wbits, cf.abits) == (10, 224, 4, 4)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 4)
+    assert sum(op["op"] == "conv" for op in spec) == 63
+    x = nets.synthetic_images(cf, 1, 5)
+    want = O.run_spec(spec[:-1], x, float_conv="device")
+    m = engine.ResidualFusedModel(spec[:-1])
+    m.kernel_log = []
+    got = host(m(dev(x)))
+    np.testing.assert_array_equal(got, want)
+    assert len(m.kernel_log) == 63 and "generic" not in m.kernel_log, m.kernel_log
+    # the softmax output through the general interpreter agrees too
+    probs = host(engine.GraphModel(spec)(dev(x)))
+    np.testing.assert_allclose(probs, O.softmax(want), atol=1e-6)
+
+
 @pytest.mark.parametrize("code,wb,ab", [("44", 4, 4), ("bb", None, None)])
 def test_residual_fused_model_on_trained_checkpoint(code, wb, ab):
     spec = nets.spec_from_keras_npz(os.path.join(GOLD, "resnet3_full_%s.npz" % code), wb, ab)
@@ -622,8 +684,10 @@ def test_ternary_layers(in_act):
         layer.input_domain = "binary" if in_act is BIN_ACT else ("quantized", in_act["nb"])
         np.testing.assert_array_equal(host(layer(dev(x))), want)
     else:
+        # unit-variance float inputs, K = 576: the float32 FMA chain (what any float32 convolution does, TF's
+        # included) is 1.13e-5 * max(1, |y|) away from the float64-accumulated ideal here (measured): 2x band
         got = host(layer(dev(x)))
-        assert np.all(np.abs(got.astype(np.float64) - want) <= 1e-5 * np.maximum(1, np.abs(want)) * 4)
+        within(got, want, 2.0)
     dk = rng.uniform(-1, 1, (64, 10)).astype(F32)
     d = qnn_amd.TernaryDense(10)
     d.build((None, 64))
@@ -680,8 +744,10 @@ def test_mnist_resnet_zero_padding():
 # ---------------------------------------------------------------------------
 # full-size (batch 4096) size-independent properties
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("idx", [1, 2])
+@pytest.mark.parametrize("idx", [1, 2, 3])
 def test_full_batch_properties(idx, impl):
+    if idx == 3 and impl == _abi.IMPL_VALU:
+        pytest.skip("VGG-large at batch 4096 on the VALU kernels alone takes minutes; covered at N=2")
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     fused = engine.FusedModel(spec)
@@ -694,8 +760,25 @@ def test_full_batch_properties(idx, impl):
     assert torch.equal(y_perm, y[perm])
     assert torch.equal(fused(x[100:137].contiguous()), y[100:137])
     # the three engines agree bit for bit at full size
-    assert torch.equal(engine.LayerModel(spec)(x[:512].contiguous()), y[:512])
+    assert torch.equal(engine.LayerModel(spec)(x[:512 if idx < 3 else 64].contiguous()), y[:512 if idx < 3 else 64])
     # and the head of the batch equals the oracle
     want = O.run_spec(spec, host(x[:4]), float_conv="device")
     np.testing.assert_array_equal(host(y[:4]), want)
     assert bool(torch.isfinite(y).all())
+
+
+def test_full_batch_properties_config5_residual_engine():
+    """Config 5 at its per-GPU batch (64 images of 224x224, nres = 10): batch independence of the fused residual
+    engine (any sub-batch and any permutation give the same rows), finite outputs, head of the batch == oracle."""
+    cf = nets.baseline_config(4)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 4)[:-1]           # logits
+    m = engine.ResidualFusedModel(spec)
+    N = 64
+    x = dev(nets.synthetic_images(cf, N, 98))
+    y = m(x)
+    perm = torch.randperm(N, device="cuda")
+    assert torch.equal(m(x[perm].contiguous()), y[perm])
+    assert torch.equal(m(x[10:13].contiguous()), y[10:13])
+    assert bool(torch.isfinite(y).all())
+    want = O.run_spec(spec, host(x[:1]), float_conv="device")
+    np.testing.assert_array_equal(host(y[:1]), want)

@@ -1,0 +1,145 @@
+"""GPU parity against vectors produced by RUNNING the reference's own source
+(tests/golden/ref_*.npz, written by tests/golden/make_fixtures_from_reference.py; see
+tests/test_reference_fixtures.py for what those vectors pin and what they cannot).
+
+Bar: bit-exact for the elementwise ops, the ternary layers and every grid x grid dense
+layer; |got - ref| <= 1e-5 * max(1, |ref|) (multiplier 1) wherever the reference's
+float32 lr-multiplier trick or a float-input contraction is involved; whole networks:
+final outputs within that band of what models/vgg.py / models/resnet.py returned.
+Everything goes through the C ABI (ctypes -> libqnn_hip.so).
+"""
+import numpy as np
+import pytest
+import torch
+
+import qnn_amd
+from qnn_amd import _abi, engine
+import ref_fixtures as R
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+def tol(ref):
+    return 1e-5 * np.maximum(1.0, np.abs(ref.astype(np.float64)))
+
+
+def same_bits(a, b):
+    a, b = np.asarray(a, F32), np.asarray(b, F32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_elementwise_ops_bit_exact_vs_reference():
+    d = R.ops()
+    x = d["ops_x"]
+    xd = dev(x)
+    np.testing.assert_array_equal(host(qnn_amd.binary_tanh(xd)), d["ops_binary_tanh"])
+    np.testing.assert_array_equal(host(qnn_amd.binary_sigmoid(xd)), d["ops_binary_sigmoid"])
+    np.testing.assert_array_equal(host(qnn_amd.binarize(xd, H=1.)), d["ops_binarize_H1"])
+    np.testing.assert_array_equal(host(qnn_amd.binarize(xd, H=0.5)), d["ops_binarize_H05"])
+    for nb in (2, 3, 4, 5, 8, 16):
+        assert same_bits(host(qnn_amd.quantized_tanh(xd, nb)), d["ops_quantized_tanh_nb%d" % nb]), nb
+        assert same_bits(host(qnn_amd.quantize(xd, nb)), d["ops_quantize_nb%d" % nb]), nb
+    for i in range(3):
+        xt = d["tern_x%d" % i]
+        np.testing.assert_array_equal(host(qnn_amd.ternary_tanh(dev(xt))), d["tern_ternary_tanh%d" % i])
+        if np.abs(xt).max() <= 1.0:
+            np.testing.assert_array_equal(host(qnn_amd.ternarize(dev(xt))), d["tern_ternarize%d" % i])
+        # weights live in [-H, H] (Clip constraint): ternarize of the clipped tensor is ternary_tanh's value
+        xc = np.clip(xt, -1, 1)
+        np.testing.assert_array_equal(host(qnn_amd.ternarize(dev(xc))), d["tern_ternary_tanh%d" % i])
+    np.testing.assert_array_equal(host(qnn_amd.ternary_tanh(dev(x[:33]))), d["tern_edge"])
+
+
+def _layer_for(c, kern, bias):
+    if c.get("dense"):
+        cls = {"binary": qnn_amd.BinaryDense, "quantized": qnn_amd.QuantizedDense,
+               "ternary": qnn_amd.TernaryDense}[c["kind"]]
+        layer = cls(kern.shape[1], **({"nb": c["nb"]} if c["kind"] == "quantized" else {}))
+        layer.build((None, kern.shape[0]))
+    else:
+        kh, kw, ci, co = kern.shape
+        cls = {"binary": qnn_amd.BinaryConv2D, "quantized": qnn_amd.QuantizedConv2D,
+               "ternary": qnn_amd.TernaryConv2D}[c["kind"]]
+        layer = cls(filters=co, kernel_size=(kh, kw), strides=tuple(c["strides"]), padding=c["padding"],
+                    use_bias=c["use_bias"], H=1., **({"nb": c["nb"]} if c["kind"] == "quantized" else {}))
+        layer.build((None, 8, 8, ci))
+    assert float(layer.kernel_lr_multiplier) == pytest.approx(c["klm"], rel=1e-7)    # build(): Glorot
+    layer.set_weights([kern] + ([bias] if bias is not None else []))
+    return layer
+
+
+def _domain(c, x):
+    """Input-domain hint for the packed kernels when the fixture's input lies on an activation grid."""
+    if c["input"] in ("image", "float"):
+        return None
+    if c["kind"] == "binary":
+        return "binary"
+    if c["kind"] == "ternary" and not c.get("dense"):
+        return None                                    # inputs are {-1, 0, 1}: not a quantized_tanh grid
+    for nb in (2, 3, 4, 8):                            # the narrowest quantized_tanh grid the values lie on
+        k = x.astype(np.float64) * 2.0 ** (nb - 1)
+        if np.array_equal(k, np.rint(k)) and k.min() >= -2 ** (nb - 1) and k.max() <= 2 ** (nb - 1) - 1:
+            return ("quantized", nb)
+    return None
+
+
+@pytest.mark.parametrize("tag", [c["tag"] for c in R.index()["layers"]])
+def test_layer_call_vs_reference(tag):
+    d, cases = R.layer_cases()
+    c = [k for k in cases if k["tag"] == tag][0]
+    kern, bias = R.trained(c)
+    x = d[tag + "_x"]
+    layer = _layer_for(c, kern, bias)
+    outs = [host(layer(dev(x)))]                       # generic float32 call() surface
+    dom = _domain(c, x)
+    if dom is not None:
+        layer.input_domain = dom                       # packed XNOR / int4 / int8 kernels
+        outs.append(host(layer(dev(x))))
+        assert same_bits(outs[0], outs[1])
+    got = outs[0]
+    if c.get("dense") or c["kind"] == "ternary":
+        ref = d[tag + "_y"]
+        if c["input"] in ("grid", "gridT"):
+            assert same_bits(got, ref)                 # no trick in these layers: exact sums
+        else:
+            assert np.all(np.abs(got.astype(np.float64) - ref) <= tol(ref))
+        return
+    for prom in ("nep50", "legacy"):
+        ref = d["%s_y_%s" % (tag, prom)]
+        assert np.all(np.abs(got.astype(np.float64) - ref) <= tol(ref)), prom
+
+
+@pytest.mark.parametrize("tag", R.net_names())
+def test_network_vs_reference(tag):
+    cf, spec, x, y_ref, trace = R.net(tag)
+    float_acts = cf.network_type in ("qnn", "bnn", "tnn", "float")
+    engines = [engine.GraphModel, engine.ResidualFusedModel, engine.LayerModel]
+    if cf.architecture == "VGG" and cf.network_type not in ("full-tnn",):
+        engines.insert(0, engine.FusedModel)
+    outs = {}
+    for cls in engines:
+        outs[cls.__name__] = host(cls(spec)(dev(x)))
+    first = outs[engines[0].__name__]
+    for name, got in outs.items():
+        if cf.architecture == "VGG":
+            assert same_bits(got, first), name          # engines agree bit for bit (logits + BN)
+        else:
+            np.testing.assert_allclose(got, first, atol=1e-6, err_msg=name)     # softmax: exp ulp
+        if float_acts:
+            assert np.abs(got - y_ref).max() <= 1e-5, name
+        elif tag == "vgg_fullqnn88_w":
+            # 8-bit activations: the reference's own trick noise flips 166 of 348 160 codes by one LSB
+            # relative to exact integer arithmetic (tests/test_reference_fixtures.py); the logits move
+            assert np.abs(got - y_ref).max() <= 2e-2, name
+        else:
+            assert np.all(np.abs(got.astype(np.float64) - y_ref) <= tol(y_ref)), name

@@ -34,9 +34,16 @@ def _worker(rank, world, port, total, out):
         x = torch.rand((total, 4, 4, 3), generator=g)
         y = shard.sharded_forward(_fake_forward, x, rank, world)
         lo, hi, _ = shard.shard_bounds(total, rank, world)
-        m = shard.allreduce_mean_abs((x * 4 - 2)[lo:hi])      # unpadded rows of this rank
+        xx = (x * 4 - 2)[lo:hi]                                # unpadded rows of this rank
+        m = shard.allreduce_mean_abs(xx)
+        # the pair ternary_ops.ternary_tanh all-reduces between its two kernels when the batch is sharded
+        ws = torch.stack([xx.clamp(-1, 1).abs().double().sum(), torch.tensor(float(xx.numel()), dtype=torch.float64)])
+        untouched = shard.allreduce_sum_count(ws.clone())      # outside a sharded context: no exchange
+        with shard.sharded():
+            shard.allreduce_sum_count(ws)
         if rank == 0:
-            torch.save({"y": y, "m": m}, out)
+            torch.save({"y": y, "m": m, "m2": (ws[0] / ws[1]).float(), "count": ws[1],
+                        "local_count": untouched[1]}, out)
     finally:
         dist.destroy_process_group()
 
@@ -67,3 +74,5 @@ def test_two_ranks_equal_single_rank(tmp_path):
         assert torch.equal(got["y"], want)
         ref = (x * 4 - 2).clamp(-1, 1).abs().double().mean().float()
         assert abs(float(got["m"]) - float(ref)) < 1e-6
+        assert abs(float(got["m2"]) - float(ref)) < 1e-6
+        assert float(got["count"]) == total * 48 and float(got["local_count"]) < total * 48

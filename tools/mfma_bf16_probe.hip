@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_bf16_probe tools/mfma_bf16_probe.hip   (run on the GPU box; the executable is not committed)
 // What does v_mfma_f32_32x32x16_bf16 compute, bit for bit?  Compare with
 //  H1: round_to_f32( C + sum_k a_k*b_k )   (exact sum, one rounding)
 //  H2: sequential fp32 FMA chain k = 0..15 starting from C

@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_probe tools/mfma_probe.hip   (run on the GPU box; the executable is not committed)
 // Probe the A/B operand lane maps of v_mfma_i32_32x32x32_i8 and _16x16x64_i8 on gfx950.
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_f32 tools/ubench_f32.hip   (run on the GPU box; the executable is not committed)
 // f32 MFMA 32x32x2: sustained cycles per MFMA vs number of accumulator chains and waves/SIMD (random operands).
 #include <hip/hip_runtime.h>
 #include <stdio.h>

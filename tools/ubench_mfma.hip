@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_mfma tools/ubench_mfma.hip   (run on the GPU box; the executable is not committed)
 // How much VALU work co-executes with MFMA of different types on gfx950?
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_mfma2 tools/ubench_mfma2.hip   (run on the GPU box; the executable is not committed)
 // Do a MFMA-only wave and a VALU-only wave on the same SIMD overlap (gfx950)?
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_mix tools/ubench_mix.hip   (run on the GPU box; the executable is not committed)
 // Does int-VALU work of one wave hide under the i8 MFMAs of the other waves on a SIMD when
 // every wave alternates bursts of both (the shape of the conv main loops)?  gfx950.
 #include <hip/hip_runtime.h>

@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_shape tools/ubench_shape.hip   (run on the GPU box; the executable is not committed)
 // i8 MFMA shape vs sustained rate on random operands (DVFS): 32x32x32 vs 16x16x64, gfx950.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
