@@ -153,21 +153,23 @@ def step_bytes(abi, st, N, H, W):
     return nbytes(st["x_store"], pix_in, cin) + nbytes(st["out_store"], pix_out, cout), Ho, Wo
 
 
-def time_launch(torch, launch, reps=20, lead=4):
+def time_launch(torch, launch, reps=20, lead=4, rounds=3):
     """Average duration of one launch, HIP events on the launching stream.  The first event is recorded
     BEHIND a few queued launches, so the host's launch latency is not inside the measured interval:
     (ev1 - ev0) / reps is the kernel's own duration, the figure rocprofv3's kernel trace reports."""
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    out = None
-    for _ in range(lead):
-        out = launch()
-    ev0.record()
-    for _ in range(reps):
-        out = launch()
-    ev1.record()
-    torch.cuda.synchronize()
-    return ev0.elapsed_time(ev1) / reps, out
+    out, times = None, []
+    for _ in range(rounds):              # the median of a few rounds: the first one can still see the clock ramp
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        for _ in range(lead):
+            out = launch()
+        ev0.record()
+        for _ in range(reps):
+            out = launch()
+        ev1.record()
+        torch.cuda.synchronize()
+        times.append(ev0.elapsed_time(ev1) / reps)
+    return sorted(times)[len(times) // 2], out
 
 
 def layer_roof_ms(k):
@@ -284,7 +286,7 @@ def main_rank(args):
         torch.cuda.synchronize()
         groups = {}
         for c in model.capture:
-            ms, _ = time_launch(torch, c["launch"], reps=8, lead=2)
+            ms, _ = time_launch(torch, c["launch"], reps=8, lead=2, rounds=1)
             g = groups.setdefault((c["kernel"], c["shape"]), dict(kernel=c["kernel"], shape=c["shape"], ms_total=0.0,
                                                                   launches=0, bytes=c["bytes"], macs=c["macs"],
                                                                   pipe=c["pipe"]))

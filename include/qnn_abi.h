@@ -106,6 +106,10 @@ const char* qnn_last_error(void);
  * (XNOR+popcount / v_dot8 / v_dot4), 2 = prefer the int8 MFMA implicit GEMM.
  * Process-wide; results are bit-identical across families. */
 int         qnn_set_conv_impl(int impl);
+/* Kernel-selection switches for A/B measurements and tests; every setting gives bit-identical results.
+ *   "strip" (default 1): row-walking kernel for the 3x3 stride-1 int4 layers with 16 / 32 channels;
+ *                        0 = the tile kernel (k_conv_mfma_small) takes them. */
+int         qnn_set_option(const char* key, int value);
 
 /* ---- elementwise activation clips on float32 tensors --------------------- */
 /* binary_ops.binary_tanh, layers/binary_ops.py:37-51 */

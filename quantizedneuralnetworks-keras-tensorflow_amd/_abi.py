@@ -18,7 +18,7 @@ W_FLOAT, W_BINARY, W_QUANT, W_TERNARY = 0, 1, 2, 3
 FN_NONE, FN_BINARY_TANH, FN_QUANTIZED_TANH, FN_TERNARY_TANH, FN_GRID = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "qnn_version", "qnn_last_error", "qnn_last_kernel", "qnn_set_conv_impl",
+    "qnn_version", "qnn_last_error", "qnn_last_kernel", "qnn_set_conv_impl", "qnn_set_option",
     "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
     "qnn_ternary_abs_sum_f32", "qnn_ternary_apply_f32",
     "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32",
@@ -48,7 +48,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB
+    # QNN_LIB: an alternative build of the same ABI (tools/build_variant.py, A/B kernel experiments only)
+    return os.environ.get("QNN_LIB") or _build.LIB
 
 
 def load():
@@ -61,7 +62,7 @@ def load():
         raise QnnError(
             "libqnn_hip.so is not built (%s). Run `python -c \"import __graft_entry__ as g; "
             "g.build()\"` (needs hipcc). There is no CPU fallback." % path)
-    if _build.built_hash() != _build.source_hash() and os.environ.get("QNN_ALLOW_STALE_LIB") != "1":
+    if path == _build.LIB and _build.built_hash() != _build.source_hash() and os.environ.get("QNN_ALLOW_STALE_LIB") != "1":
         raise QnnError(
             "libqnn_hip.so was built from other sources than the ones in csrc/ (stamp %s, sources %s). Rebuild: "
             "`python -c \"import __graft_entry__ as g; g.build()\"`." % (_build.built_hash(), _build.source_hash()))
@@ -71,6 +72,7 @@ def load():
     lib.qnn_last_error.restype = ctypes.c_char_p
     lib.qnn_last_kernel.restype = ctypes.c_char_p
     lib.qnn_set_conv_impl.argtypes = [ci]
+    lib.qnn_set_option.argtypes = [ctypes.c_char_p, ci]
     lib.qnn_binary_tanh_f32.argtypes = [vp, vp, sz, vp]
     lib.qnn_quantized_tanh_f32.argtypes = [vp, vp, sz, ci, vp]
     lib.qnn_ternary_tanh_f32.argtypes = [vp, vp, sz, vp, vp]
@@ -113,6 +115,11 @@ def set_conv_impl(impl):
     global _conv_impl
     check(load().qnn_set_conv_impl(int(impl)), "qnn_set_conv_impl")
     _conv_impl = int(impl)
+
+
+def set_option(key, value):
+    """Kernel-selection switch (qnn_set_option): "strip" 0 / 1.  Results are bit-identical under every setting."""
+    check(load().qnn_set_option(key.encode(), int(value)), "qnn_set_option")
 
 
 def conv_impl():

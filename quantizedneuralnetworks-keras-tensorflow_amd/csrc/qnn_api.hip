@@ -2,6 +2,7 @@
 #include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "qnn_common.h"
 
@@ -9,7 +10,19 @@ namespace {
 thread_local char g_error[512] = "";
 thread_local char g_kernel[64] = "";
 std::atomic<int> g_conv_impl{0};
+std::atomic<int> g_option[QNN_OPT_COUNT] = {{1}, {0}, {0}, {0}};     // strip kernel on
 }  // namespace
+
+int qnn_option(int which) { return g_option[which].load(std::memory_order_relaxed); }
+
+extern "C" int qnn_set_option(const char* key, int value) {
+    if (key && strcmp(key, "strip") == 0) {
+        g_option[QNN_OPT_STRIP].store(value ? 1 : 0, std::memory_order_relaxed);
+        return QNN_OK;
+    }
+    qnn_set_error("qnn_set_option: unknown key '%s'", key ? key : "(null)");
+    return QNN_EINVAL;
+}
 
 int qnn_conv_impl_pref() { return g_conv_impl.load(std::memory_order_relaxed); }
 

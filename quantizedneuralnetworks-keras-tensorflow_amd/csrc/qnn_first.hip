@@ -156,25 +156,43 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 3 : 2)) void k_conv_first_mfma(Conv
 // Wp % 8 == 0); POOL==1: 32 pixels in a row (needs W % 32 == 0): tiles never straddle
 // the image edge, so no store needs a bounds check.  No barriers: the LDS tile is
 // private to the wave.
+#ifndef QNN_FIRST_PRIO
+// 1 = a wave's MFMA phase runs at raised priority (s_setprio 1): the other waves' epilogue VALU then only takes the
+// issue slots the matrix chain leaves (measured 141 -> 133 us; raising the epilogue instead: 135 us; 0 = off)
+#define QNN_FIRST_PRIO 1
+#endif
+
+constexpr int first_lds_row_stride(int roww) {          // smallest stride >= roww with stride % 32 == 16
+    int rs = (roww / 32) * 32 + 16;
+    return rs >= roww ? rs : rs + 32;
+}
+
 template <int CIN, int NT, int OUT, int POOL>
 __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom g, EpiArgs e,
                                                            const float* __restrict__ x,
                                                            const float* __restrict__ wq,
                                                            void* __restrict__ y, long total_q,
                                                            int tiles, int tiles_per_row,
-                                                           FastDiv fd_tpr, uint32_t x_bytes) {
+                                                           FastDiv fd_tpr, uint32_t x_bytes, int abl) {
     constexpr int K = 9 * CIN;
     constexpr int KS = (K + 1) / 2;
     constexpr int TROWS = (POOL == 2) ? 4 : 3;        // conv rows + halo
     constexpr int TCOLS = (POOL == 2) ? 18 : 34;      // conv cols + halo
-    constexpr int TE = TROWS * TCOLS * CIN;           // floats per tile
+    constexpr int ROWW = TCOLS * CIN;                 // floats per tile row
+    // LDS row stride.  The 32 lanes of an operand read sit on two tile rows (POOL == 2: lrow in {0,1},
+    // lcol in 0..15): word = lrow*RS + lcol*CIN + const.  lcol*CIN covers 16 distinct banks and so does the
+    // second row iff RS == 16 (mod 32) (3*16 == 16, 1*16 == 16): conflict-free ds_read_b32.  With the natural
+    // stride 54 (CIN 3) two banks collided in every read (42 % of the LDS cycles were conflict cycles).
+    constexpr int RS = (POOL == 2) ? first_lds_row_stride(ROWW) : ROWW;
+    constexpr int TE = TROWS * ROWW;                  // floats staged per tile
+    constexpr int TL = TROWS * RS;                    // LDS words per tile
     constexpr int NJ = (TE + 63) / 64;                // staging loads per lane
     constexpr bool PACKED = OUT == QNN_STORE_I4 || OUT == QNN_STORE_I8;
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     const int lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float* lds = reinterpret_cast<float*>(smem_f) + wv * TE;          // wave-private tile
+    float* lds = reinterpret_cast<float*>(smem_f) + wv * TL;          // wave-private tile
     const int wave_id = blockIdx.x * 4 + wv;
     const int nwaves = gridDim.x * 4;
     const int cbase = blockIdx.y * (NT * 32);
@@ -184,6 +202,14 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
     const float mfold = (PACKED && !binary) ? e.act_m : 1.0f;
 
     // ---- per-lane constants ----
+    // The block's NT*32 filters are one contiguous run of wq: copy it to LDS with coalesced loads and let every
+    // lane pick its operands from there (lane stride K = 27 or 9 words: odd, so conflict-free).  Fetched straight
+    // from global memory the 28 operand loads of a wave touch 64 different cache lines each -- 1 792 address
+    // cycles per wave, 9 us of a 141 us launch for the 12 waves of a CU (measured: the launch time extrapolates
+    // to 11-14 us at zero images).
+    float* fw = reinterpret_cast<float*>(smem_f) + 4 * TL;
+    for (int i = threadIdx.x; i < NT * 32 * K; i += 256) fw[i] = wq[(long)cbase * K + i];
+    __syncthreads();
     LaneEpi ke[NT];
     FoldEpi fe[NT];
     float wb[NT][KS];
@@ -197,19 +223,20 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int k = 2 * s + lh;
-            float w = k < K ? wq[(long)(cbase + nt * 32 + li) * K + k] : 0.0f;
+            float w = k < K ? fw[(nt * 32 + li) * K + k] : 0.0f;
             wb[nt][s] = flip ? -w : w;
         }
     }
     // staging: element ej = lane + 64*j of the [TROWS][TCOLS][CIN] tile
-    int st_goff[NJ];
+    int st_goff[NJ], st_lidx[NJ];
     unsigned long long mX[NJ], mT[NJ], mB[NJ], mL[NJ], mR[NJ];   // lanes outside the tile / on each halo edge
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int ej = lane + 64 * j;
-        const int r = ej / (TCOLS * CIN), rem = ej - r * (TCOLS * CIN);
+        const int r = ej / ROWW, rem = ej - r * ROWW;
         const int col = rem / CIN, ch = rem - col * CIN;
         st_goff[j] = ((r * g.W + col) * CIN + ch) * 4;
+        st_lidx[j] = r * RS + rem;
         mX[j] = __ballot(ej >= TE);
         mT[j] = __ballot(r == 0);
         mB[j] = __ballot(r == TROWS - 1);
@@ -226,9 +253,10 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
         const int k = 2 * s + lh;
         const int kk = k < K ? k : 0;
         const int tap = kk / CIN, ch = kk - tap * CIN;
-        op_idx[s] = ((lrow + tap / 3) * TCOLS + (lcol + tap % 3)) * CIN + ch;
+        op_idx[s] = (lrow + tap / 3) * RS + (lcol + tap % 3) * CIN + ch;
     }
-    const bool kpad = (K & 1) && lh == 1;          // lane half 1 of the last k-step is padding
+    // (lane half 1 of the last k-step is padding when K is odd: its filter operand is 0.0f and its A operand is
+    // tap 0 / channel 0 of the lane's own receptive field, a value the true sum contains anyway)
     // packed outputs: after the in-register transpose lane (li & 7) / (li & 3) of an octet /
     // quad holds one finished word; its word offset from the tile's first stored pixel
     int lane_off = 0;
@@ -272,7 +300,7 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
     auto stage_write = [&](int) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            if (lane + 64 * j < TE) lds[lane + 64 * j] = stg[j];
+            if (lane + 64 * j < TE) lds[st_lidx[j]] = stg[j];
     };
     // When the wave stride is a whole number of images, a wave sees the same tile position
     // (hence the same halo lanes) in every image: the per-lane byte offsets (or the out-of-range
@@ -284,12 +312,16 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
     const int x_step = img_step * g.H * g.W * CIN * 4;
     const long q_step = (long)img_step * ((POOL == 2) ? g.Hp * g.Wp : g.H * g.W);
     int pvoff[NJ];
+    // the k-th tile of this wave sits k*x_step bytes further: a SCALAR offset on the buffer load (no VALU);
+    // clamped to the wave's last tile, because the two loads issued past the end must stay inside the tensor
+    const int my_tiles = (tiles - wave_id + nwaves - 1) / nwaves;
+    int kload = 0;
     auto stage_load_next = [&]() {                                  // periodic mode: the next tile of this wave
+        const int soff = min(kload, my_tiles - 1) * x_step;
+        ++kload;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            stg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, pvoff[j], 0, 0));
-            pvoff[j] += x_step;
-        }
+        for (int j = 0; j < NJ; ++j)
+            stg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, pvoff[j], soff, 0));
     };
 
     // Order inside one iteration (tile i): MFMAs on the operands fetched during the previous
@@ -335,7 +367,6 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
                                  : ((long)n * g.H + oy0) * g.W + ox0;
         }
         uint32_t* ytile = reinterpret_cast<uint32_t*>(y) + q_base * e.ocw;   // packed outputs only
-        if (kpad) av[KS - 1] = 0.0f;
 #pragma unroll
         for (int nc = 0; nc < NT; nc += 2) {
             v16f acc[2];
@@ -343,17 +374,31 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+#if QNN_FIRST_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+#elif QNN_FIRST_PRIO == 2
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wb[nc + u][s], acc[u], 0, 0, 0);
-            if (nc + 2 >= NT) {
+#if QNN_FIRST_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#elif QNN_FIRST_PRIO == 2
+            __builtin_amdgcn_s_setprio(1);
+#endif
+            if (nc + 2 >= NT && !(abl & 2)) {
                 __builtin_amdgcn_sched_barrier(0);
                 stage_write(0);
                 fetch_operands();
                 if (periodic) stage_load_next(); else stage_load(min(t + 2 * nwaves, tiles - 1));
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (abl & 1) {                       // timing experiment: no epilogue arithmetic, one raw store
+                if (acc[0][0] + acc[1][0] == 123.456f) ytile[lane_off + nc * 4] = 1u;
+                continue;
             }
             auto bn = [&](float v, const FoldEpi& f) {
                 return __fadd_rn(__fmul_rn(__fadd_rn(v, f.nb), f.ninv), f.nshift);
@@ -441,13 +486,15 @@ int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float
             if (lblocks > lmax) lblocks = lmax;
             const dim3 lgrid((unsigned)lblocks, (unsigned)ny);
             const FastDiv fd_tpr = qnn_fastdiv((uint32_t)tpr);
-            const size_t lds_bytes = (size_t)4 * ((g.pool == 2 ? 4 * 18 : 3 * 34) * CIN) * 4;   // one tile per wave
+            const size_t lds_bytes = (size_t)4 * (g.pool == 2 ? 4 * first_lds_row_stride(18 * CIN) : 3 * 34 * CIN) * 4   // one tile per wave
+                                     + (size_t)NT * 32 * 9 * CIN * 4;                                                  // + the block's filters
+            static const int abl = getenv("QNN_FIRST_ABL") ? atoi(getenv("QNN_FIRST_ABL")) : 0;   // timing experiments only
 #define FIRST_LDS_CASE(OUT)                                                                      \
             if (e.out_store == OUT) {                                                            \
                 if (g.pool == 2)                                                                 \
-                    hipLaunchKernelGGL((k_conv_first_lds<CIN, NT, OUT, 2>), lgrid, block, lds_bytes, s, g, e, xf, wq, y, total_q, (int)ntiles, tpr, fd_tpr, x_bytes); \
+                    hipLaunchKernelGGL((k_conv_first_lds<CIN, NT, OUT, 2>), lgrid, block, lds_bytes, s, g, e, xf, wq, y, total_q, (int)ntiles, tpr, fd_tpr, x_bytes, abl); \
                 else                                                                             \
-                    hipLaunchKernelGGL((k_conv_first_lds<CIN, NT, OUT, 1>), lgrid, block, lds_bytes, s, g, e, xf, wq, y, total_q, (int)ntiles, tpr, fd_tpr, x_bytes); \
+                    hipLaunchKernelGGL((k_conv_first_lds<CIN, NT, OUT, 1>), lgrid, block, lds_bytes, s, g, e, xf, wq, y, total_q, (int)ntiles, tpr, fd_tpr, x_bytes, abl); \
                 return 0;                                                                        \
             }
             FIRST_LDS_CASE(QNN_STORE_F32)

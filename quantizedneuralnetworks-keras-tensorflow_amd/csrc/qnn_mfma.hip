@@ -20,6 +20,8 @@
 // minor": rows 4g..4g+3 of the tile are one window and land in four consecutive
 // accumulator registers of ONE lane (C/D layout row = (r&3) + 8*(r>>2) + 4*(lane>>5)),
 // so pooling is an in-lane max -- no cross-lane traffic.
+#include <math.h>
+
 #include "qnn_mfma_common.h"
 
 namespace {
@@ -661,6 +663,14 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
             ms.x_bytes = (uint32_t)xb_; ms.w_bytes = (uint32_t)wb_; ms.ablate = 0;
             EpiArgs es = e;
             es.scale = e.scale * (1.0f / 256.0f);            // both operands carry *16
+            // row-walking kernel: Cout == Cin, and the residual's post-scale (models/resnet.py:128: 0.5) a power
+            // of two so that it folds exactly into the activation's code scale
+            int pexp = 0;
+            const bool pow2 = !e.res || (e.post_scale > 0.0f && frexpf(e.post_scale, &pexp) == 0.5f);
+            if (qnn_option(QNN_OPT_STRIP) && g.cout == g.cin && pow2) {
+                snprintf(name, name_len, "strip_i4_c%d", g.cin);
+                if (qnn_launch_strip(g.cin, ms, es, x, w->d_mfma, y, s) == 0) return 0;
+            }
             snprintf(name, name_len, "mfma_i4_small_c%d", g.cin);
             const int rc_ = qnn_launch_small(g.cin, ms, es, x, w->d_mfma, y, s);
             if (rc_ == 0) return 0;

@@ -239,3 +239,6 @@ int qnn_launch_wres(int x_store, const MfmaGeom& mg, const EpiArgs& e, const voi
                     void* y, hipStream_t s);
 int qnn_launch_small(int cin, const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w,
                      void* y, hipStream_t s);
+int qnn_launch_strip(int cin, const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w,
+                     void* y, hipStream_t s);
+int qnn_option(int which);   // qnn_api.hip: QNN_OPT_* switches set through qnn_set_option()

@@ -518,7 +518,9 @@ def test_one_bit_layers_on_the_matrix_pipe():
 
 
 @pytest.mark.parametrize("cin,cout,hw,n", [(16, 16, (20, 32), 3), (16, 32, (7, 16), 2), (32, 32, (9, 16), 5),
-                                           (32, 64, (5, 48), 2), (16, 16, (33, 16), 9)])
+                                           (32, 64, (5, 48), 2), (16, 16, (33, 16), 9), (16, 16, (224, 224), 2),
+                                           (32, 32, (112, 112), 3), (16, 16, (5, 16), 1), (32, 32, (1, 32), 2),
+                                           (16, 16, (2, 48), 70)])
 def test_small_channel_layers_on_the_matrix_pipe(cin, cout, hw, n):
     """3x3 int4 layers with 16 / 32 input channels: both MFMA operands in registers (no LDS);
     ragged tile counts, every border class, 2- and 4-bit and binary output codes."""
@@ -529,11 +531,16 @@ def test_small_channel_layers_on_the_matrix_pipe(cin, cout, hw, n):
     op = {"op": "conv", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (3, 3, cin, cout)).astype(F32),
           "bias": (rng.standard_normal(cout) * 0.05).astype(F32), "strides": (1, 1), "padding": "same"}
     bn = _rand_bn(rng, cout, 9 * cin * 0.12)
-    for act in (Q(4), Q(2), BIN_ACT):
-        want = _oracle_group(x, op, bn, act, 1)
-        got, kern = _run_group(x, Q(4), op, bn, act, 1, _abi.STORE_I4)
-        assert kern == "mfma_i4_small_c%d" % cin, kern
-        np.testing.assert_array_equal(got, want)
+    for strip in (1, 0):                 # row-walking kernel (Cout == Cin only) and the tile kernel
+        _abi.set_option("strip", strip)
+        try:
+            for act in (Q(4), Q(2), BIN_ACT):
+                want = _oracle_group(x, op, bn, act, 1)
+                got, kern = _run_group(x, Q(4), op, bn, act, 1, _abi.STORE_I4)
+                assert kern == ("strip_i4_c%d" if strip and cin == cout else "mfma_i4_small_c%d") % cin, kern
+                np.testing.assert_array_equal(got, want)
+        finally:
+            _abi.set_option("strip", 1)
 
 
 def test_vgg_large_8bit_small_batch(impl):
@@ -604,10 +611,10 @@ def test_residual_fused_model(nt, wb, ab, nres):
         if (nt, wb, ab) == ("full-qnn", 4, 4):
             # the 16- and 32-channel stages (incl. their residual merges) run on the register-operand
             # MFMA kernel, the 64-channel stage on the LDS-weights one
-            assert m.kernel_log.count("mfma_i4_small_c16") >= 2 * nres, m.kernel_log
+            assert m.kernel_log.count("strip_i4_c16") >= 2 * nres, m.kernel_log
             # (the first 32-channel block starts with a stride-2 conv; its second conv merges the
             # float32 projection shortcut, which the kernel reads directly)
-            assert m.kernel_log.count("mfma_i4_small_c32") >= 2 * nres - 1, m.kernel_log
+            assert m.kernel_log.count("strip_i4_c32") >= 2 * nres - 1, m.kernel_log
             assert any(k.startswith("mfma_i4_areg") for k in m.kernel_log), m.kernel_log
 
 
@@ -624,8 +631,17 @@ def test_residual_fused_model_at_imagenet_geometry():
     m.kernel_log = []
     got = host(m(dev(x)))
     np.testing.assert_array_equal(got, want)
-    for k in ("mfma_i4_small_c16", "mfma_i4_small_c32", "mfma_i4_areg64x64"):
+    for k in ("strip_i4_c16", "strip_i4_c32", "mfma_i4_areg64x64"):
         assert k in m.kernel_log, m.kernel_log
+    # the tile kernel (strip switch off) gives the same logits
+    _abi.set_option("strip", 0)
+    try:
+        m2 = engine.ResidualFusedModel(spec)
+        m2.kernel_log = []
+        np.testing.assert_array_equal(host(m2(dev(x))), want)
+        assert "mfma_i4_small_c16" in m2.kernel_log and "strip_i4_c16" not in m2.kernel_log
+    finally:
+        _abi.set_option("strip", 1)
 
 
 def test_config5_imagenet224_resnet_nres10_at_spec():

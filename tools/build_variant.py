@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""A/B kernel experiments: build csrc/variants/libqnn_<name>.so that differs from the in-tree library only in
+the extra compiler flags given for ONE translation unit.  Select it at run time with QNN_LIB=<path>.
+    python tools/build_variant.py wps2 qnn_first.hip -DQNN_FIRST_WPS=2
+Variants are build artefacts (git-ignored); they travel to the GPU box with gpurun like the main library."""
+import importlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+b = importlib.import_module("quantizedneuralnetworks-keras-tensorflow_amd._build")
+
+
+def main():
+    name, tu, flags = sys.argv[1], sys.argv[2], sys.argv[3:]
+    b.build()                                      # the other objects come from the regular build
+    vdir = os.path.join(b.CSRC, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    obj = os.path.join(vdir, "%s_%s.o" % (tu[:-4], name))
+    subprocess.run([b._hipcc()] + b.CFLAGS + flags + ["-c", os.path.join(b.CSRC, tu), "-o", obj], check=True)
+    objs = [obj if os.path.basename(s) == tu else os.path.join(b.OBJDIR, os.path.basename(s)[:-4] + ".o")
+            for s in b._sources()]
+    lib = os.path.join(vdir, "libqnn_%s.so" % name)
+    subprocess.run([b._hipcc()] + b.LDFLAGS + ["-o", lib] + objs, check=True)
+    print(lib)
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.log 2>&1 || exit 2
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.log 2>&1 || exit 3
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $ARGS > $OUT/bench_sq.log 2>&1 || exit 4
-python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+python3 $ROOT/tools/summarize_profile.py $OUT $OUT/traffic.json $OUT/bench_trace.log > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep the merged-back payload small
 find $OUT -name "*.db" -delete; find $OUT -name "*agent_info*" -delete

@@ -40,8 +40,43 @@ def main(root):
                 print("%-72s n=%d %s" % (k, len(next(iter(cs.values()))), " ".join(parts)))
 
 
-def traffic_json(root, out_path):
-    """Per-kernel average FETCH_SIZE / WRITE_SIZE (KiB per dispatch) keyed by template name."""
+# qnn_last_kernel() tag -> regular expression of the kernel's demangled rocprofv3 name
+TAG_PATTERNS = [
+    (r"^mfma_f32_first_cin(\d)$", r"^k_conv_first_(lds|mfma)<\1,"),
+    (r"^mfma_i(\d)_areg64x64$", r"^k_conv_mfma_areg<\1,"),
+    (r"^mfma_i(\d)_wres256x64$", r"^k_conv_mfma_wres<\1,"),
+    (r"^mfma_i4_small_c(\d+)$", r"^k_conv_mfma_small<\1,"),
+    (r"^strip_i4_c(\d+)$", r"^k_conv_strip<\1,"),
+    (r"^mfma_i(\d)_(\d+)x(\d+)$", None),          # tile sizes -> waves, handled below
+    (r"^dense_i(\d)$", r"^k_dense_packed<\1,"),
+    (r"^dense_bin$", r"^k_dense_packed<1,"),
+    (r"^dense_f32$", r"^k_dense_f32in"),
+    (r"^xnor_f32_cw(\d+)$", r"^k_conv_xnor_f32<\1>"),
+    (r"^xnor_pk_cw(\d+)", r"^k_conv_xnor_pk<\1,"),
+    (r"^ps_", r"^k_conv_ps<"),
+    (r"^generic$", r"^k_conv_generic"),
+]
+
+
+def rocprof_names_for(tag, names):
+    import re
+    for tpat, kpat in TAG_PATTERNS:
+        m = re.match(tpat, tag)
+        if not m:
+            continue
+        if kpat is None:
+            bits, bm, bn = m.group(1), int(m.group(2)) // 64, int(m.group(3)) // 64
+            kre = re.compile(r"^k_conv_mfma(16)?<%s, %d, %d," % (bits, bm, bn))
+        else:
+            kre = re.compile(m.expand(kpat))
+        return [n for n in names if kre.match(n)]
+    return []
+
+
+def traffic_json(root, out_path, bench_json=None):
+    """Per-kernel average FETCH_SIZE / WRITE_SIZE (KiB per dispatch) and trace duration, keyed by the rocprofv3
+    kernel name (`by_kernel`) and by the tag qnn_last_kernel() reports (`by_tag`, what bench.py looks up; a tag
+    is only listed when exactly one profiled kernel matches it)."""
     import json
     res = {}
     for sub, key in (("pmc_fetch", "fetch_kb"), ("pmc_write", "write_kb")):
@@ -51,10 +86,31 @@ def traffic_json(root, out_path):
                 agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
             for k, v in agg.items():
                 res.setdefault(k, {})[key] = sum(v) / len(v)
-    json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
+    for f in find(os.path.join(root, "trace"), "kernel_trace.csv"):
+        dur = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for k, v in dur.items():
+            res.setdefault(k, {})["avg_us"] = sum(v) / len(v) / 1e3
+            res[k]["calls"] = len(v)
+    tags = []
+    if bench_json and os.path.exists(bench_json):
+        for line in open(bench_json):
+            line = line.strip()
+            if line.startswith("{"):
+                try:
+                    tags = [k["kernel"] for k in json.loads(line).get("kernels", [])]
+                except ValueError:
+                    pass
+    by_tag = {}
+    for tag in dict.fromkeys(tags):
+        names = rocprof_names_for(tag, list(res))
+        if len(names) == 1:
+            by_tag[tag] = dict(res[names[0]], rocprof_kernel=names[0])
+    json.dump({"by_tag": by_tag, "by_kernel": res}, open(out_path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
     main(sys.argv[1])
     if len(sys.argv) > 2:
-        traffic_json(sys.argv[1], sys.argv[2])
+        traffic_json(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
