@@ -108,7 +108,9 @@ const char* qnn_last_error(void);
 int         qnn_set_conv_impl(int impl);
 /* Kernel-selection switches for A/B measurements and tests; every setting gives bit-identical results.
  *   "strip" (default 1): row-walking kernel for the 3x3 stride-1 int4 layers with 16 / 32 channels;
- *                        0 = the tile kernel (k_conv_mfma_small) takes them. */
+ *                        0 = the tile kernel (k_conv_mfma_small) takes them.
+ *   "strip64" (default -1): the same kernel for 64-channel layers: -1 = only where a residual is merged (the LDS-weight kernel
+ *                        is faster without one), 0 never, 1 always. */
 int         qnn_set_option(const char* key, int value);
 
 /* ---- elementwise activation clips on float32 tensors --------------------- */

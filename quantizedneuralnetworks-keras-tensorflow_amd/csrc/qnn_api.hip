@@ -10,7 +10,7 @@ namespace {
 thread_local char g_error[512] = "";
 thread_local char g_kernel[64] = "";
 std::atomic<int> g_conv_impl{0};
-std::atomic<int> g_option[QNN_OPT_COUNT] = {{1}, {0}, {0}, {0}};     // strip kernel on
+std::atomic<int> g_option[QNN_OPT_COUNT] = {{1}, {-1}, {0}, {0}};    // strip kernel on, Cin 64: auto
 }  // namespace
 
 int qnn_option(int which) { return g_option[which].load(std::memory_order_relaxed); }
@@ -18,6 +18,10 @@ int qnn_option(int which) { return g_option[which].load(std::memory_order_relaxe
 extern "C" int qnn_set_option(const char* key, int value) {
     if (key && strcmp(key, "strip") == 0) {
         g_option[QNN_OPT_STRIP].store(value ? 1 : 0, std::memory_order_relaxed);
+        return QNN_OK;
+    }
+    if (key && strcmp(key, "strip64") == 0) {
+        g_option[QNN_OPT_STRIP64].store(value < 0 ? -1 : value ? 1 : 0, std::memory_order_relaxed);
         return QNN_OK;
     }
     qnn_set_error("qnn_set_option: unknown key '%s'", key ? key : "(null)");

@@ -57,7 +57,7 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                         const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len);
 int qnn_conv_impl_pref();
 int qnn_option(int which);
-enum { QNN_OPT_STRIP = 0, QNN_OPT_COUNT = 4 };
+enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_COUNT = 4 };
 
 // ---- division by a launch-constant via multiply-high (dividends < 2^31) ----------
 struct FastDiv {

@@ -286,6 +286,87 @@ __global__ __launch_bounds__(64) void k_dense_f32in(EpiArgs e, int N, int cin, i
 }
 
 // ---------------------------------------------------------------------------
+// 1x1 convolution of a packed int4 tensor with float32 output: the linear projection shortcuts of
+// models/resnet.py:117-124 (kernel_size=1, strides=2, no BN, no activation; their value is added to a BN
+// output, so it is kept in float32).  HBM-bound: the output is 8x the input.  Eight lanes share a pixel,
+// each owns cout/8 consecutive output channels with their filters resident in VGPRs and stores them with
+// 16-byte stores: one wave instruction writes 8 pixels x cout floats = a contiguous 1 or 2 KB.  (The
+// pixel-stationary kernel below stores one float per lane and instruction, 64 different lines each:
+// 119 us for the 224^2 -> 112^2 projection against 20 us of HBM time.)
+// ---------------------------------------------------------------------------
+template <int CW, int CPL>      // packed words per input pixel, output channels per lane
+__global__ __launch_bounds__(kBlock) void k_conv_pw_f32(ConvGeom g, EpiArgs e, const uint32_t* __restrict__ x,
+                                                        const uint32_t* __restrict__ wp,
+                                                        float* __restrict__ y, long total_q) {
+    const int sub = threadIdx.x & 7;                        // channel group of this lane
+    const int c0 = sub * CPL;
+    uint32_t wv[CPL][CW];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int k = 0; k < CW; ++k) wv[c][k] = wp[(size_t)(c0 + c) * CW + k];
+    float bs[CPL], iv[CPL], sh[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        bs[c] = e.bias ? e.bias[c0 + c] : 0.0f;
+        iv[c] = e.bn_inv ? e.bn_inv[c0 + c] : 1.0f;
+        sh[c] = e.bn_inv ? e.bn_shift[c0 + c] : 0.0f;
+    }
+    const bool has_bias = e.bias != nullptr, has_bn = e.bn_inv != nullptr;
+    const long stride_q = (long)gridDim.x * (kBlock / 8);
+    for (long q = (long)blockIdx.x * (kBlock / 8) + (threadIdx.x >> 3); q < total_q; q += stride_q) {
+        const uint32_t qrow = qnn_div((uint32_t)q, g.fd_wp);           // n*Ho + oy  (Wp == Wo, no pooling)
+        const int ox = (int)((uint32_t)q - qrow * (uint32_t)g.Wp);
+        const uint32_t n = qnn_div(qrow, g.fd_hp);
+        const int oy = (int)(qrow - n * (uint32_t)g.Hp);
+        const uint32_t* xp = x + (((size_t)n * g.H + (size_t)oy * g.stride) * g.W + (size_t)ox * g.stride) * CW;
+        uint32_t xv[CW];
+        if constexpr (CW == 2) { const uint2 t = *reinterpret_cast<const uint2*>(xp); xv[0] = t.x; xv[1] = t.y; }
+        else if constexpr (CW == 4) { const uint4 t = *reinterpret_cast<const uint4*>(xp); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w; }
+        else {
+#pragma unroll
+            for (int k = 0; k < CW; ++k) xv[k] = xp[k];
+        }
+        float out[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) acc = qnn_dot_i4(xv[k], wv[c][k], acc);
+            float v = __fmul_rn((float)acc, e.scale);
+            if (has_bias) v = __fadd_rn(v, bs[c]);
+            if (has_bn) v = __fadd_rn(__fmul_rn(v, iv[c]), sh[c]);
+            out[c] = v;
+        }
+        float* yp = y + (size_t)q * g.cout + c0;
+#pragma unroll
+        for (int c = 0; c < CPL; c += 4)
+            *reinterpret_cast<float4*>(yp + c) = make_float4(out[c], out[c + 1], out[c + 2], out[c + 3]);
+    }
+}
+
+// 0 = launched
+int try_launch_pw_f32(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
+                      hipStream_t s) {
+    if (g.kh != 1 || g.kw != 1 || g.pool != 1 || e.res || e.out_store != QNN_STORE_F32 || e.fn != QNN_FN_NONE) return 1;
+    if (w->store != QNN_STORE_I4 || g.pt != 0 || g.pl != 0) return 1;
+    const int cw = g.cw, cpl = g.cout / 8;
+    if (g.cout % 8 != 0 || g.cin % 8 != 0) return 1;
+    const long total_q = (long)g.N * g.Ho * g.Wo;
+    long blocks = (total_q + kBlock / 8 - 1) / (kBlock / 8);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+#define PW_CASE(CW_, CPL_)                                                                                   \
+    if (cw == CW_ && cpl == CPL_) {                                                                          \
+        hipLaunchKernelGGL((k_conv_pw_f32<CW_, CPL_>), dim3((unsigned)blocks), dim3(kBlock), 0, s, g, e,      \
+                           (const uint32_t*)x, w->d_packed, (float*)y, total_q);                             \
+        return 0;                                                                                            \
+    }
+    PW_CASE(2, 4) PW_CASE(2, 8) PW_CASE(4, 4) PW_CASE(4, 8) PW_CASE(8, 8) PW_CASE(8, 16)
+#undef PW_CASE
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
 // pixel-stationary kernel
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int quad_max_i(int v) {
@@ -984,6 +1065,10 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
                            (const float*)x, w->d_wq, (float*)y);
         launched = true;
         snprintf(name, sizeof(name), "dense_f32");
+    }
+    if (!launched && !dense && x_store == QNN_STORE_I4 && try_launch_pw_f32(g, e, x, w, y, s) == 0) {
+        launched = true;
+        snprintf(name, sizeof(name), "pw_i4_f32");
     }
     if (!launched && pref != 1 && !dense)          // residual epilogues: only where the MFMA kernel has one
         launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;

@@ -24,6 +24,8 @@
 
 #include "qnn_mfma_common.h"
 
+
+
 namespace {
 
 // XS: QNN_STORE_I8 or QNN_STORE_I4 (storage of x; weights are always int8 bytes here)
@@ -649,7 +651,38 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     if (!w->d_mfma) return 1;
     if (x_store != QNN_STORE_I8 && x_store != QNN_STORE_I4) return 1;
     static const bool small_off = getenv("QNN_MFMA_SMALL_OFF") != nullptr;   // A/B switch, read once
-    // small-channel 3x3 int4 layers: both operands in registers
+    // 3x3 stride-1 int4 layers with 16 / 32 / 64 input channels: row-walking strip kernel (qnn_mfma_strip.hip).
+    // The residual's post-scale (models/resnet.py:128: 0.5) must be a power of two so that it folds exactly into the
+    // activation's code scale.
+    {
+        int pexp = 0;
+        const bool pow2 = !e.res || (e.post_scale > 0.0f && frexpf(e.post_scale, &pexp) == 0.5f);
+        const int cmul = g.cin == 16 ? 16 : 32;
+        const bool shape = x_store == QNN_STORE_I4 && w->store == QNN_STORE_I4 &&
+                           (g.cin == 16 || g.cin == 32 || g.cin == 64) && g.kh == 3 && g.kw == 3 && g.stride == 1 &&
+                           g.pt == 1 && g.pl == 1 && g.pool == 1 && e.out_store == QNN_STORE_I4 &&
+                           (g.cout % cmul) == 0 && pow2 &&
+                           (!e.res || (e.res_store == QNN_STORE_I4 && e.res_cw == e.ocw) ||
+                            (e.res_store == QNN_STORE_F32 && e.res_cw == g.cout));
+        // Cin 64 (auto): the layers that merge a residual.  Measured, 64 x 56^2 / 4096 x 16^2 pixels: with the merge
+        // 18.8 / 65.7 us here against 36.4 / 122.8 us on the LDS-weight kernel, without it 16.3 / 54.6 against 14.1 / 47.3.
+        const int s64 = qnn_option(QNN_OPT_STRIP64);
+        const bool want = g.cin == 64 ? (s64 == 1 || (s64 < 0 && e.res != nullptr)) : true;
+        if (shape && want && qnn_option(QNN_OPT_STRIP)) {
+            MfmaGeom ms;
+            ms.g = g; ms.kc = 1; ms.steps = 0; ms.x_pix_bytes = g.cin / 2;
+            ms.total_q = (long)g.N * g.H * g.W;
+            const double wb_ = (double)g.cout * 9 * g.cin;
+            if (wb_ < 2.0e9) {
+                ms.x_bytes = 0; ms.w_bytes = (uint32_t)wb_; ms.ablate = 0;
+                EpiArgs es = e;
+                es.scale = e.scale * (1.0f / 256.0f);        // both operands carry *16
+                snprintf(name, name_len, "strip_i4_c%d", g.cin);
+                if (qnn_launch_strip(g.cin, ms, es, x, w->d_mfma, y, s) == 0) return 0;
+            }
+        }
+    }
+    // small-channel 3x3 int4 layers on the tile kernel (both operands in registers)
     if (x_store == QNN_STORE_I4 && w->store == QNN_STORE_I4 && (g.cin == 16 || g.cin == 32) && g.kh == 3 &&
         g.kw == 3 && g.stride == 1 && g.pt == 1 && g.pl == 1 && g.pool == 1 && (g.W % 16) == 0 &&
         e.out_store == QNN_STORE_I4 && (g.cout % (g.cin == 16 ? 16 : 32)) == 0 &&
@@ -663,14 +696,6 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
             ms.x_bytes = (uint32_t)xb_; ms.w_bytes = (uint32_t)wb_; ms.ablate = 0;
             EpiArgs es = e;
             es.scale = e.scale * (1.0f / 256.0f);            // both operands carry *16
-            // row-walking kernel: Cout == Cin, and the residual's post-scale (models/resnet.py:128: 0.5) a power
-            // of two so that it folds exactly into the activation's code scale
-            int pexp = 0;
-            const bool pow2 = !e.res || (e.post_scale > 0.0f && frexpf(e.post_scale, &pexp) == 0.5f);
-            if (qnn_option(QNN_OPT_STRIP) && g.cout == g.cin && pow2) {
-                snprintf(name, name_len, "strip_i4_c%d", g.cin);
-                if (qnn_launch_strip(g.cin, ms, es, x, w->d_mfma, y, s) == 0) return 0;
-            }
             snprintf(name, name_len, "mfma_i4_small_c%d", g.cin);
             const int rc_ = qnn_launch_small(g.cin, ms, es, x, w->d_mfma, y, s);
             if (rc_ == 0) return 0;

@@ -197,6 +197,8 @@ LAYER_CASES = [
     ("i4_32_64_s2", (2, 16, 16, 32), 64, 3, 2, "quantized", 4, Q(4), "ps_i4_cw4_k3"),
     ("i4_128_32", (1, 8, 8, 128), 32, 3, 1, "quantized", 4, Q(4), "ps_i4_cw16_k3"),
     ("i4_1x1_s2", (2, 16, 16, 16), 32, 1, 2, "quantized", 4, Q(4), "ps_i4_cw2_k1"),
+    ("i4_1x1_s2_32_64", (3, 15, 9, 32), 64, 1, 2, "quantized", 4, Q(4), "ps_i4_cw4_k1"),
+    ("i4_1x1_s1_16_64", (2, 5, 7, 16), 64, 1, 1, "quantized", 4, Q(4), "ps_i4_cw2_k1"),
     ("i4_w2_a4", (2, 8, 8, 64), 64, 3, 1, "quantized", 2, Q(4), "ps_i4_cw8_k3"),
     ("i4_w4_a2", (2, 8, 8, 64), 64, 3, 1, "quantized", 4, Q(2), "ps_i4_cw8_k3"),
     ("i4_generic_c24", (2, 8, 8, 24), 24, 3, 1, "quantized", 4, Q(4), "generic"),
@@ -258,7 +260,10 @@ def test_lowbit_conv_layer_bit_exact(case, pool, impl):
         pytest.skip("no pool window")
     # 1) plain float32 output, bias only (the Keras call() surface)
     got, kern = _run_group(x, in_act, op, None, None, pool, _abi.STORE_F32)
-    assert kern.startswith(kernel_name), kern
+    if k == 1 and wnb == 4 and in_act == Q(4) and pool == 1 and impl != _abi.IMPL_MFMA:
+        assert kern == "pw_i4_f32", kern          # 1x1 int4 -> float32: the projection-shortcut kernel
+    else:
+        assert kern.startswith(kernel_name), kern
     want = _oracle_group(x, op, None, None, pool)
     np.testing.assert_array_equal(got, want)
     # 2) fused BN + activation (+pool), packed output, every storage that can hold it
@@ -520,10 +525,13 @@ def test_one_bit_layers_on_the_matrix_pipe():
 @pytest.mark.parametrize("cin,cout,hw,n", [(16, 16, (20, 32), 3), (16, 32, (7, 16), 2), (32, 32, (9, 16), 5),
                                            (32, 64, (5, 48), 2), (16, 16, (33, 16), 9), (16, 16, (224, 224), 2),
                                            (32, 32, (112, 112), 3), (16, 16, (5, 16), 1), (32, 32, (1, 32), 2),
-                                           (16, 16, (2, 48), 70)])
+                                           (16, 16, (2, 48), 70), (16, 16, (9, 20), 3), (32, 32, (7, 56), 2),
+                                           (64, 64, (56, 56), 3), (64, 64, (8, 8), 5), (64, 128, (5, 23), 2),
+                                           (16, 16, (3, 7), 2), (64, 64, (1, 1), 3)])
 def test_small_channel_layers_on_the_matrix_pipe(cin, cout, hw, n):
-    """3x3 int4 layers with 16 / 32 input channels: both MFMA operands in registers (no LDS);
-    ragged tile counts, every border class, 2- and 4-bit and binary output codes."""
+    """3x3 int4 layers with 16 / 32 / 64 input channels.  Row-walking strip kernel (any width: ragged last strip,
+    one-pixel images, chunked rows) and, with the switch off, the tile kernels; every border class, 2- and 4-bit
+    and binary output codes."""
     rng = np.random.default_rng(cin * 1000 + cout + hw[0])
     H, W = hw
     pre = rng.standard_normal((n, H, W, cin)).astype(F32)
@@ -531,16 +539,31 @@ def test_small_channel_layers_on_the_matrix_pipe(cin, cout, hw, n):
     op = {"op": "conv", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (3, 3, cin, cout)).astype(F32),
           "bias": (rng.standard_normal(cout) * 0.05).astype(F32), "strides": (1, 1), "padding": "same"}
     bn = _rand_bn(rng, cout, 9 * cin * 0.12)
-    for strip in (1, 0):                 # row-walking kernel (Cout == Cin only) and the tile kernel
+    for strip in (1, 0):
         _abi.set_option("strip", strip)
         try:
             for act in (Q(4), Q(2), BIN_ACT):
                 want = _oracle_group(x, op, bn, act, 1)
                 got, kern = _run_group(x, Q(4), op, bn, act, 1, _abi.STORE_I4)
-                assert kern == ("strip_i4_c%d" if strip and cin == cout else "mfma_i4_small_c%d") % cin, kern
+                if strip and cin < 64:
+                    assert kern == "strip_i4_c%d" % cin, kern
+                elif cin < 64 and W % 16 == 0:
+                    assert kern == "mfma_i4_small_c%d" % cin, kern
+                else:
+                    assert not kern.startswith("strip"), kern
                 np.testing.assert_array_equal(got, want)
         finally:
             _abi.set_option("strip", 1)
+    if cin == 64:      # without a bias (the ResNet layers have none) and as "never" / "always" for Cin 64
+        op2 = dict(op, bias=None)
+        for s64 in (0, 1, -1):
+            _abi.set_option("strip64", s64)
+            try:
+                got, kern = _run_group(x, Q(4), op2, bn, Q(4), 1, _abi.STORE_I4)
+                assert kern.startswith("strip") == (s64 == 1), (s64, kern)     # auto: only with a residual merge
+                np.testing.assert_array_equal(got, _oracle_group(x, op2, bn, Q(4), 1))
+            finally:
+                _abi.set_option("strip64", -1)
 
 
 def test_vgg_large_8bit_small_batch(impl):
