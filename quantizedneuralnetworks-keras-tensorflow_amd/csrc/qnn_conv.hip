@@ -28,6 +28,7 @@
 #define QNN_XNOR_U 16
 #endif
 
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -565,53 +566,34 @@ int launch_dense(const void* x, const qnn_weights* w, const EpiArgs& e, void* y,
 //            bytes per pixel.  Out-of-image taps are skipped by uniform branches, so no
 //            correction table is needed here.
 // ---------------------------------------------------------------------------
-template <int CW>   // packed words per pixel (cin / 32), even
-__global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e, int in_fn, int TR,
-                                                          int strips, const float* __restrict__ x,
-                                                          const uint32_t* __restrict__ wp,
-                                                          float* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) char smem_x[];
-    uint2* tile = reinterpret_cast<uint2*>(smem_x);            // [(TR+2) rows][W][CW/2] uint2
-    constexpr int PAIRS = CW / 2;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = blockIdx.x / strips;
-    const int r0 = (blockIdx.x - n * strips) * TR;               // first output row of the strip
-    const int rows_out = min(TR, g.H - r0);
-    const int cbase = blockIdx.y * 64;
-    const float thr = (in_fn == QNN_FN_GRID) ? 0.0f : 0x1p-24f;  // binary_tanh(x) = +1 iff x > 2^-24
-
-    // ---- phase 1: binarize rows r0-1 .. r0+rows_out into LDS ----
-    const int row_lo = max(r0 - 1, 0), row_hi = min(r0 + rows_out, g.H - 1);   // inclusive, in-image
-    const int groups = (row_hi - row_lo + 1) * g.W * PAIRS;     // 64-channel groups to convert
-    const float* xin = x + ((size_t)n * g.H + row_lo) * g.W * g.cin;
-    uint2* tdst = tile + (size_t)(row_lo - (r0 - 1)) * g.W * PAIRS;
-    constexpr int U = QNN_XNOR_U;      // loads in flight per lane: phase 1 is latency-bound otherwise
-    for (int gi = wave * U; gi < groups; gi += 4 * U) {
-        float v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = (gi + u < groups) ? xin[(size_t)(gi + u) * 64 + lane] : -1.0f;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned long long m = __ballot(v[u] > thr);
-            if (lane == u && gi + u < groups) tdst[gi + u] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
-        }
+// Lane SEL of (mlo, mhi) takes the wave's 64-bit mask of (v > thr); the other lanes keep their values.  One block of
+// assembly: compare into VCC, v_writelane_b32 both halves with an immediate lane select (two SGPR operands would break
+// the constant-bus limit; clang 22 has no writelane builtin).  The s_nop covers the VALU-writes-SGPR -> v_writelane
+// wait states, which the compiler's hazard recogniser does not insert inside inline assembly (without it the masks
+// were wrong on gfx950).
+template <int SEL>
+__device__ __forceinline__ void qnn_mask_to_lane(float v, float thr, uint32_t& mlo, uint32_t& mhi) {
+    asm volatile("v_cmp_gt_f32 vcc, %2, %3\n\ts_nop 4\n\tv_writelane_b32 %0, vcc_lo, %4\n\tv_writelane_b32 %1, vcc_hi, %4"
+                 : "+v"(mlo), "+v"(mhi) : "v"(v), "v"(thr), "n"(SEL) : "vcc");
+}
+// masks of U compares -> lane u holds the 64-bit mask of value u (compile-time unrolled)
+template <int I, int U>
+__device__ __forceinline__ void qnn_collect_masks(const float (&v)[U], float thr, uint32_t& mlo, uint32_t& mhi) {
+    if constexpr (I < U) {
+        qnn_mask_to_lane<I>(v[I], thr, mlo, mhi);
+        qnn_collect_masks<I + 1, U>(v, thr, mlo, mhi);
     }
-    // ---- this lane's filter ----
-    uint32_t wreg[9 * CW];
-    const uint32_t* wsrc = wp + (size_t)(cbase + lane) * (9 * CW);
-#pragma unroll
-    for (int k = 0; k < 9 * CW; ++k) wreg[k] = wsrc[k];
-    const int c = cbase + lane;
-    const float bias = e.bias ? e.bias[c] : 0.0f;
-    const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
-    const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
-    __syncthreads();
+}
 
-    // ---- phase 2: every wave walks whole rows.  Validity of the 3x3 taps is wave-uniform:
-    // the row class (top / middle / bottom) is fixed along a row and the column class only
-    // differs for the first and last pixel, so each class gets its own straight-line code
-    // (compile-time tap masks): nine LDS broadcast reads issued up front, no branches. ----
+// phase 2 of the layer-surface XNOR kernels: every wave walks whole rows of the strip whose packed rows sit in `tile`.
+// Validity of the 3x3 taps is wave-uniform: the row class (top / middle / bottom) is fixed along a row and the column
+// class only differs for the first and last pixel, so each class gets its own straight-line code (compile-time tap
+// masks): nine LDS broadcast reads issued up front, no branches.
+template <int CW>
+__device__ __forceinline__ void xnor_f32_rows(const ConvGeom& g, const EpiArgs& e, const uint2* tile,
+                                              const uint32_t (&wreg)[9 * CW], float bias, float inv, float shift,
+                                              int n, int r0, int rows_out, int wave, int c, float* __restrict__ y) {
+    constexpr int PAIRS = CW / 2;
     const bool has_bn = e.bn_inv != nullptr;
     const float kf_cin = (float)g.cin;
     auto pixel = [&](auto rm_c, auto cm_c, const uint2* rowbase, float* yrow, int ox) {
@@ -673,6 +655,56 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
     }
 }
 
+template <int CW>   // packed words per pixel (cin / 32), even
+__global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e, int in_fn, int TR,
+                                                          int strips, const float* __restrict__ x,
+                                                          const uint32_t* __restrict__ wp,
+                                                          float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    uint2* tile = reinterpret_cast<uint2*>(smem_x);            // [(TR+2) rows][W][CW/2] uint2
+    constexpr int PAIRS = CW / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x / strips;
+    const int r0 = (blockIdx.x - n * strips) * TR;               // first output row of the strip
+    const int rows_out = min(TR, g.H - r0);
+    const int cbase = blockIdx.y * 64;
+    const float thr = (in_fn == QNN_FN_GRID) ? 0.0f : 0x1p-24f;  // binary_tanh(x) = +1 iff x > 2^-24
+
+    // ---- phase 1: binarize rows r0-1 .. r0+rows_out into LDS ----
+    const int row_lo = max(r0 - 1, 0), row_hi = min(r0 + rows_out, g.H - 1);   // inclusive, in-image
+    const int groups = (row_hi - row_lo + 1) * g.W * PAIRS;     // 64-channel groups to convert
+    const float* xin = x + ((size_t)n * g.H + row_lo) * g.W * g.cin;
+    uint2* tdst = tile + (size_t)(row_lo - (r0 - 1)) * g.W * PAIRS;
+    constexpr int U = QNN_XNOR_U;      // loads in flight per lane: phase 1 is latency-bound otherwise
+    for (int gi = wave * U; gi < groups; gi += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (gi + u < groups) ? xin[(size_t)(gi + u) * 64 + lane] : -1.0f;
+        // the wave's 64-bit compare mask IS the packed pixel group: lane u collects the mask of group gi + u
+        // (v_writelane, no exec games), then U lanes store U groups with one LDS instruction
+        uint32_t mlo = 0, mhi = 0;
+        qnn_collect_masks<0, U>(v, thr, mlo, mhi);
+        if (lane < U && gi + lane < groups) tdst[gi + lane] = make_uint2(mlo, mhi);
+    }
+    // ---- this lane's filter ----
+    uint32_t wreg[9 * CW];
+    const uint32_t* wsrc = wp + (size_t)(cbase + lane) * (9 * CW);
+#pragma unroll
+    for (int k = 0; k < 9 * CW; ++k) wreg[k] = wsrc[k];
+    const int c = cbase + lane;
+    const float bias = e.bias ? e.bias[c] : 0.0f;
+    const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
+    const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+    __syncthreads();
+    xnor_f32_rows<CW>(g, e, tile, wreg, bias, inv, shift, n, r0, rows_out, wave, c, y);
+}
+
+// (Measured dead end, round 2: the same layer as a PERSISTENT double-buffered pipeline -- workgroups walking strips, the
+// next strip's float32 rows requested into registers before the current strip is computed, filters fetched once per
+// workgroup -- ran 129 / 30.5 us on the CIFAR B0 / C0 layers against 100 / 27.5 us for this kernel: 78-151 VGPRs cut the
+// occupancy to 3-6 waves per SIMD, and many small independent workgroups overlap their load and compute phases better.)
+
 // ---------------------------------------------------------------------------
 // Fused-pipeline 1-bit conv: packed bits in, packed bits out (BN + binary_tanh + optional
 // 2x2 max-pool fused).  Same structure as k_conv_xnor_f32 (lane = output channel, filter in
@@ -705,10 +737,13 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_pk(ConvGeom g, EpiArgs e, 
     uint2* tdst = tile + (size_t)(row_lo - (r0 - 1)) * g.W * PAIRS;
     for (int i = threadIdx.x; i < nent; i += kBlock) tdst[i] = xin[i];
 
-    uint32_t wreg[9 * CW];
-    const uint32_t* wsrc = wp + (size_t)(cbase + lane) * (9 * CW);
-#pragma unroll
-    for (int k = 0; k < 9 * CW; ++k) wreg[k] = wsrc[k];
+    // filters through LDS (coalesced copy, odd row pitch), as in k_conv_xnor_f32
+    constexpr int WROW = 9 * CW + 1;
+    uint32_t* wfil = reinterpret_cast<uint32_t*>(tile + (size_t)(TRP * POOL + 2) * g.W * PAIRS);
+    for (int i = threadIdx.x; i < 64 * 9 * CW; i += kBlock) {
+        const int fc = i / (9 * CW);
+        wfil[fc * WROW + (i - fc * (9 * CW))] = wp[(size_t)cbase * (9 * CW) + i];
+    }
     const int c = cbase + lane;
     const float bias = e.bias ? e.bias[c] : 0.0f;
     const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
@@ -716,6 +751,9 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_pk(ConvGeom g, EpiArgs e, 
     const bool has_bn = e.bn_inv != nullptr;
     const float kf_cin = (float)g.cin;
     __syncthreads();
+    uint32_t wreg[9 * CW];
+#pragma unroll
+    for (int k = 0; k < 9 * CW; ++k) wreg[k] = wfil[lane * WROW + k];
 
     // mask of one conv pixel (tile row oy, column ox) for border class (RM, CM)
     auto pixel_mask = [&](auto rm_c, auto cm_c, int oy, int ox) -> unsigned long long {
@@ -829,7 +867,7 @@ int try_launch_xnor_pk(const ConvGeom& g, const EpiArgs& e, const void* x, const
     int TRP = g.Hp;
     while ((size_t)(TRP * g.pool + 2) * g.W * cw * 4 > 32768 && TRP > 1) TRP = (TRP + 1) / 2;
     const int strips = (g.Hp + TRP - 1) / TRP;
-    const size_t lds = (size_t)(TRP * g.pool + 2) * g.W * cw * 4;
+    const size_t lds = (size_t)(TRP * g.pool + 2) * g.W * cw * 4 + (size_t)64 * (9 * cw + 1) * 4;   // rows + the block's filters
     const dim3 grid((unsigned)(g.N * strips), (unsigned)(g.cout / 64)), block(kBlock);
     snprintf(name, name_len, "xnor_pk_cw%d", cw);
 #define XPK_CASE(CW_)                                                                              \
@@ -864,8 +902,8 @@ int try_launch_xnor_f32(const ConvGeom& g, const EpiArgs& e, int in_fn, const fl
     else if (tr_env == 0 && TR > 8 && (TR % 8) == 0) TR = 8;    // measured: more, smaller items overlap load and compute better
     const int strips = (g.H + TR - 1) / TR;
     const size_t lds = (size_t)(TR + 2) * g.W * cw * 4;
-    const dim3 grid((unsigned)(g.N * strips), (unsigned)(g.cout / 64)), block(kBlock);
     snprintf(name, name_len, "xnor_f32_cw%d", cw);
+    const dim3 grid((unsigned)(g.N * strips), (unsigned)(g.cout / 64)), block(kBlock);
     if (cw == 2) hipLaunchKernelGGL(k_conv_xnor_f32<2>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
     else if (cw == 4) hipLaunchKernelGGL(k_conv_xnor_f32<4>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
     else hipLaunchKernelGGL(k_conv_xnor_f32<8>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);

@@ -23,21 +23,24 @@ def main(root):
     for f in find(os.path.join(root, "trace"), "kernel_trace.csv"):
         dur = defaultdict(list)
         for r in csv.DictReader(open(f)):
-            dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            # one template instance often serves several layers: keep launches on different grids apart
+            grid = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+            dur[(short(r["Kernel_Name"]), grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         print("== kernel trace: %s" % os.path.relpath(f, root))
-        print("%-72s %8s %12s %12s %12s" % ("kernel", "calls", "avg_us", "min_us", "total_ms"))
-        for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-            print("%-72s %8d %12.2f %12.2f %12.3f" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, sum(v) / 1e6))
+        print("%-72s %-16s %8s %12s %12s %12s" % ("kernel", "grid (threads)", "calls", "avg_us", "min_us", "total_ms"))
+        for (k, grid), v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+            print("%-72s %-16s %8d %12.2f %12.2f %12.3f" % (k, grid, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3, sum(v) / 1e6))
     # counters
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         for f in find(os.path.join(root, sub), "counter_collection.csv"):
             agg = defaultdict(lambda: defaultdict(list))
             for r in csv.DictReader(open(f)):
-                agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                key = "%s [grid %s]" % (short(r["Kernel_Name"]), r.get("Grid_Size", "?"))
+                agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             print("== counters: %s (per-dispatch averages)" % os.path.relpath(f, root))
             for k, cs in sorted(agg.items()):
                 parts = ["%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(cs.items())]
-                print("%-72s n=%d %s" % (k, len(next(iter(cs.values()))), " ".join(parts)))
+                print("%-90s n=%d %s" % (k, len(next(iter(cs.values()))), " ".join(parts)))
 
 
 # qnn_last_kernel() tag -> regular expression of the kernel's demangled rocprofv3 name
