@@ -56,6 +56,7 @@ int qnn_mfma_prepare_weights(qnn_weights* w, hipStream_t s);
 int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const void* x,
                         const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len);
 int qnn_conv_impl_pref();
+int qnn_try_launch_stem(const ConvGeom& g, const EpiArgs& e, const void* x, const float* wq, void* y, hipStream_t s);
 int qnn_option(int which);
 enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_COUNT = 4 };
 

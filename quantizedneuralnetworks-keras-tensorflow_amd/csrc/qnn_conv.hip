@@ -1108,6 +1108,10 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
         launched = true;
         snprintf(name, sizeof(name), "pw_i4_f32");
     }
+    if (!launched && pref != 1 && !dense && x_store == QNN_STORE_F32 && qnn_try_launch_stem(g, e, x, w->d_wq, y, s) == 0) {
+        launched = true;                           // float-input layer with few filters (ResNet stem)
+        snprintf(name, sizeof(name), "mfma_f32_stem_cin%d", g.cin);
+    }
     if (!launched && pref != 1 && !dense)          // residual epilogues: only where the MFMA kernel has one
         launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
     if (!launched && x_store == QNN_STORE_BIN && !dense && !e.res)

@@ -658,10 +658,13 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
         int pexp = 0;
         const bool pow2 = !e.res || (e.post_scale > 0.0f && frexpf(e.post_scale, &pexp) == 0.5f);
         const int cmul = g.cin == 16 ? 16 : 32;
+        // stride 2 (the first conv of a stage: no residual, Cin 16 / 32, Cout a multiple of 32): the same walk over
+        // output rows, three fresh input rows per output row
+        const bool s1 = g.stride == 1 && g.pt == 1 && g.pl == 1 && (g.cout % cmul) == 0;
+        const bool s2 = g.stride == 2 && (g.cin == 16 || g.cin == 32) && (g.cout % 32) == 0 && !e.res;
         const bool shape = x_store == QNN_STORE_I4 && w->store == QNN_STORE_I4 &&
-                           (g.cin == 16 || g.cin == 32 || g.cin == 64) && g.kh == 3 && g.kw == 3 && g.stride == 1 &&
-                           g.pt == 1 && g.pl == 1 && g.pool == 1 && e.out_store == QNN_STORE_I4 &&
-                           (g.cout % cmul) == 0 && pow2 &&
+                           (g.cin == 16 || g.cin == 32 || g.cin == 64) && g.kh == 3 && g.kw == 3 && (s1 || s2) &&
+                           g.pool == 1 && e.out_store == QNN_STORE_I4 && pow2 &&
                            (!e.res || (e.res_store == QNN_STORE_I4 && e.res_cw == e.ocw) ||
                             (e.res_store == QNN_STORE_F32 && e.res_cw == g.cout));
         // Cin 64 (auto): the layers that merge a residual.  Measured, 64 x 56^2 / 4096 x 16^2 pixels: with the merge
@@ -677,7 +680,7 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                 ms.x_bytes = 0; ms.w_bytes = (uint32_t)wb_; ms.ablate = 0;
                 EpiArgs es = e;
                 es.scale = e.scale * (1.0f / 256.0f);        // both operands carry *16
-                snprintf(name, name_len, "strip_i4_c%d", g.cin);
+                snprintf(name, name_len, g.stride == 2 ? "strip_i4_c%d_s2" : "strip_i4_c%d", g.cin);
                 if (qnn_launch_strip(g.cin, ms, es, x, w->d_mfma, y, s) == 0) return 0;
             }
         }

@@ -258,6 +258,189 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The stride-2 3x3 layers that open a ResNet stage (models/resnet.py:108-112; no residual merge behind them): the same
+// strip walk over OUTPUT rows; an output row needs input rows 2*yy - pt .. + 2, of which only one is shared with the next
+// output row, so every output row simply requests its three input rows (one output row ahead) and widens them.
+// B operand of lane (pixel r, k-block): input pixel 2*(xs + r) - pl + dx.
+// ---------------------------------------------------------------------------------------------------------
+template <int CIN, int NT, bool BIAS>
+__global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(MfmaGeom mg, EpiArgs e,
+                                                                             const uint8_t* __restrict__ x,
+                                                                             const uint8_t* __restrict__ wq8,
+                                                                             void* __restrict__ y, int ntasks, int spr,
+                                                                             FastDiv fd_spr, int nch, FastDiv fd_nch,
+                                                                             int rc, uint32_t img_x, uint32_t img_y) {
+    constexpr int BP = CIN / 16;
+    constexpr int ST = (3 * BP + 3) / 4;
+    constexpr int PIXB = CIN / 2;
+    const ConvGeom& g = mg.g;                          // g.H, g.W: input; g.Ho, g.Wo: output
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int nbase = blockIdx.y * (16 * NT);
+    int dxs[ST], hbs[ST];
+    bool kok[ST];
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+        const int j = 4 * st + kq;
+        kok[st] = j < 3 * BP;
+        dxs[st] = kok[st] ? j / BP : 1;
+        hbs[st] = kok[st] ? j % BP : 0;
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
+    v4i bw[3][ST][NT];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int st = 0; st < ST; ++st)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int woff = kok[st] ? ((nbase + nt * 16 + r) * 9 + dy * 3 + dxs[st]) * CIN + hbs[st] * 16 : (int)0x80000000;
+                bw[dy][st][nt] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
+            }
+    const bool binary = e.fn == QNN_FN_BINARY_TANH;
+    const float cfold = binary ? 1.0f : e.act_m;
+    float nb[NT][4], ninv[NT][4], nshift[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = nbase + nt * 16 + 4 * kq + i;
+            nb[nt][i] = BIAS ? __fdiv_rn(e.bias[c], e.scale) : 0.0f;
+            ninv[nt][i] = __fmul_rn(__fmul_rn(e.bn_inv ? e.bn_inv[c] : 1.0f, e.scale), cfold);
+            nshift[nt][i] = __fmul_rn(e.bn_inv ? e.bn_shift[c] : 0.0f, cfold);
+        }
+    constexpr float kMagic = 12582920.0f;
+    constexpr int kMagicBits = 0x4B400008;
+    const int code_lo = kMagicBits - (int)e.act_m, code_hi = kMagicBits + (int)e.act_m - 1;
+    const int rowb2 = 2 * g.W * PIXB;                  // two input rows per output row
+    const int orowb = g.Wo * e.ocw * 4;
+    auto widen = [&](const uint2& q) -> v4i {
+        const uint4 v = make_uint4((q.x << 4) & 0xF0F0F0F0u, q.x & 0xF0F0F0F0u,
+                                   (q.y << 4) & 0xF0F0F0F0u, q.y & 0xF0F0F0F0u);
+        return __builtin_bit_cast(v4i, v);
+    };
+    for (int task = wid; task < ntasks; task += nw) {
+        const uint32_t rest = qnn_div((uint32_t)task, fd_nch);
+        const int chunk = task - (int)rest * nch;
+        const int n = (int)qnn_div(rest, fd_spr);
+        const int xs = ((int)rest - n * spr) * 16;
+        const int y0 = chunk * rc;
+        const int y1 = min(y0 + rc, g.Ho);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(x) + (size_t)n * img_x, 0, (int)img_x, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            (uint8_t*)y + (size_t)n * img_y, 0, (int)img_y, 0x00020000);
+        int voff[3][ST];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int st = 0; st < ST; ++st) {
+                const int px = 2 * (xs + r) - g.pl + dxs[st];
+                voff[dy][st] = (kok[st] && px >= 0 && px < g.W && xs + r < g.Wo)
+                                   ? ((2 * y0 - g.pt + dy) * g.W + px) * PIXB + hbs[st] * 8 : (int)0x80000000;
+            }
+        const bool pvalid = xs + r < g.Wo;
+        int ovoff = pvalid ? (y0 * g.Wo + xs + r) * e.ocw * 4 + nbase / 2 + kq * 2 : (int)0x80000000;
+        uint2 raw[2][3][ST];
+        auto load_rows = [&](uint2 (&dst)[3][ST]) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int st = 0; st < ST; ++st) {
+                    dst[dy][st] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xr, voff[dy][st], 0, 0));
+                    voff[dy][st] += rowb2;
+                }
+        };
+        load_rows(raw[0]);
+        auto body = [&](uint2 (&cur)[3][ST], uint2 (&nxt)[3][ST]) {
+            load_rows(nxt);                            // the three input rows of the next output row
+            v4i acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = v4i{0, 0, 0, 0};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int st = 0; st < ST; ++st) {
+                    const v4i xo = widen(cur[dy][st]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[dy][st][nt], xo, acc[nt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float u4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = (float)acc[nt][i];
+                    if constexpr (BIAS) v = __fadd_rn(v, nb[nt][i]);
+                    u4[i] = __fadd_rn(__fmul_rn(v, ninv[nt][i]), nshift[nt][i]);
+                }
+                int cb[4];
+                if (binary) {
+                    asm volatile("; binary_tanh codes");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cb[i] = u4[i] > 0x1p-24f ? kMagicBits + 1 : kMagicBits - 1;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int bits = __float_as_int(__fadd_rn(u4[i], kMagic));
+                        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cb[i]) : "v"(bits), "v"(code_lo), "v"(code_hi));
+                    }
+                }
+                uint32_t P = ((uint32_t)cb[1] << 4) | (uint32_t)cb[0];
+                P = ((uint32_t)cb[2] << 8) | P;
+                P = ((uint32_t)cb[3] << 12) | P;
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(P ^ 0x8888u), yr, ovoff + 8 * nt, 0, 0);
+            }
+            ovoff += orowb;
+        };
+        int yy = y0;
+        for (; yy + 2 <= y1; yy += 2) {
+            body(raw[0], raw[1]);
+            body(raw[1], raw[0]);
+        }
+        if (yy < y1) body(raw[0], raw[1]);
+    }
+}
+
+template <int CIN, int NT>
+int launch_strip_s2(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s) {
+    const ConvGeom& g = mg.g;
+    const int spr = (g.Wo + 15) / 16;
+    const int ny = g.cout / (16 * NT);
+    const double img_x = (double)g.H * g.W * (CIN / 2), img_y = (double)g.Ho * g.Wo * e.ocw * 4.0;
+    if (img_x >= 1.0e9 || img_y >= 1.0e9 || ny < 1 || ny * 16 * NT != g.cout) return 1;
+    const int wps = CIN == 16 ? 4 : 2;
+    const int blocks_cap = 256 * wps / ny > 0 ? 256 * wps / ny : 1;
+    const long nwaves = (long)blocks_cap * 4;
+    int best_rc = g.Ho, best_nch = 1;
+    double best_cost = 1e300;
+    for (int rc = g.Ho < 4 ? g.Ho : 4; rc <= g.Ho; ++rc) {
+        const int nch = (g.Ho + rc - 1) / rc;
+        const long rounds = ((long)g.N * spr * nch + nwaves - 1) / nwaves;
+        const double cost = (double)rounds * (rc + 2);
+        if (cost < best_cost) { best_cost = cost; best_rc = rc; best_nch = nch; }
+    }
+    const long ntasks_l = (long)g.N * spr * best_nch;
+    if (ntasks_l >= 2000000000L) return 1;
+    long blocks = (ntasks_l + 3) / 4;
+    if (blocks > blocks_cap) blocks = blocks_cap;
+    const dim3 grid((unsigned)blocks, (unsigned)ny), block(256);
+    if (e.bias)
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, true>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+                           spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
+                           (uint32_t)img_x, (uint32_t)img_y);
+    else
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+                           spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
+                           (uint32_t)img_x, (uint32_t)img_y);
+    return 0;
+}
+
 template <int CIN, int NT>
 int launch_strip(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s) {
     const ConvGeom& g = mg.g;
@@ -306,6 +489,10 @@ int launch_strip(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
 // cin in {16, 32, 64}, cout a multiple of 16 / 32 / 32; eligibility is checked by the caller
 int qnn_launch_strip(int cin, const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w,
                      void* y, hipStream_t s) {
+    if (mg.g.stride == 2) {
+        if (e.res) return 1;
+        return cin == 16 ? launch_strip_s2<16, 2>(mg, e, x, w, y, s) : cin == 32 ? launch_strip_s2<32, 2>(mg, e, x, w, y, s) : 1;
+    }
     if (cin == 16) return launch_strip<16, 1>(mg, e, x, w, y, s);
     if (cin == 32) return launch_strip<32, 2>(mg, e, x, w, y, s);
     return launch_strip<64, 2>(mg, e, x, w, y, s);

@@ -566,6 +566,24 @@ def test_small_channel_layers_on_the_matrix_pipe(cin, cout, hw, n):
                 _abi.set_option("strip64", -1)
 
 
+@pytest.mark.parametrize("cin,cout,hw,n", [(16, 32, (224, 224), 1), (32, 64, (112, 112), 2), (16, 32, (8, 8), 3),
+                                           (32, 64, (7, 9), 2), (16, 64, (5, 33), 2), (32, 32, (1, 1), 2), (16, 32, (2, 40), 5)])
+def test_stride2_layers_on_the_strip_kernel(cin, cout, hw, n):
+    """The stride-2 3x3 convs that open a ResNet stage (resnet.py:108-112): SAME padding is asymmetric for even sizes
+    (0 before / 1 after), symmetric for odd ones; ragged last strips; with and without a bias."""
+    rng = np.random.default_rng(cin + cout * 7 + hw[1])
+    H, W = hw
+    x = O.run_spec([Q(4)], rng.standard_normal((n, H, W, cin)).astype(F32))
+    for bias in (True, False):
+        op = {"op": "conv", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (3, 3, cin, cout)).astype(F32),
+              "bias": (rng.standard_normal(cout) * 0.05).astype(F32) if bias else None, "strides": (2, 2), "padding": "same"}
+        bn = _rand_bn(rng, cout, 9 * cin * 0.12)
+        for act in (Q(4), Q(3), BIN_ACT):
+            got, kern = _run_group(x, Q(4), op, bn, act, 1, _abi.STORE_I4)
+            assert kern == "strip_i4_c%d_s2" % cin, kern
+            np.testing.assert_array_equal(got, _oracle_group(x, op, bn, act, 1))
+
+
 def test_vgg_large_8bit_small_batch(impl):
     cf = nets.baseline_config(3)
     spec = nets.build_spec(cf, nets.SEED_BASE + 3)

@@ -46,6 +46,8 @@ def main(root):
 # qnn_last_kernel() tag -> regular expression of the kernel's demangled rocprofv3 name
 TAG_PATTERNS = [
     (r"^mfma_f32_first_cin(\d)$", r"^k_conv_first_(lds|mfma)<\1,"),
+    (r"^mfma_f32_stem_cin(\d)$", r"^k_conv_stem<\1,"),
+    (r"^pw_i4_f32$", r"^k_conv_pw_f32<"),
     (r"^mfma_i(\d)_areg64x64$", r"^k_conv_mfma_areg<\1,"),
     (r"^mfma_i(\d)_wres256x64$", r"^k_conv_mfma_wres<\1,"),
     (r"^mfma_i4_small_c(\d+)$", r"^k_conv_mfma_small<\1,"),
