@@ -140,6 +140,11 @@ int qnn_pack_f32(const float* x, void* y, size_t pixels, int channels,
 int qnn_unpack_f32(const void* x, float* y, size_t pixels, int channels,
                    int store, int nb, void* stream);
 
+/* AveragePooling2D(pool_size=size) 'valid' of a packed NHWC tensor into float32 (N, H/size, W/size, C):
+ * models/resnet.py:134 behind the last activation.  Exact window sums of the codes, one float32 division. */
+int qnn_avgpool_packed_f32(const void* x, int store, int bits, int N, int H, int W, int C, int size,
+                           float* y, void* stream);
+
 /* ---- weights -------------------------------------------------------------- */
 /*
  * Quantize + pack a layer's latent float32 kernel once (the reference re-runs

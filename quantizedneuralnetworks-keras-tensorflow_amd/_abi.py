@@ -21,7 +21,7 @@ EXPORTS = [
     "qnn_version", "qnn_last_error", "qnn_last_kernel", "qnn_set_conv_impl", "qnn_set_option",
     "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
     "qnn_ternary_abs_sum_f32", "qnn_ternary_apply_f32",
-    "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32",
+    "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32", "qnn_avgpool_packed_f32",
     "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant",
     "qnn_conv2d_forward", "qnn_dense_forward", "qnn_conv2d_forward_f32in", "qnn_conv2d_workspace_bytes",
 ]
@@ -82,6 +82,7 @@ def load():
     lib.qnn_packed_bytes.restype = sz
     lib.qnn_pack_f32.argtypes = [vp, vp, sz, ci, ci, ci, ci, vp]
     lib.qnn_unpack_f32.argtypes = [vp, vp, sz, ci, ci, ci, vp]
+    lib.qnn_avgpool_packed_f32.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
     lib.qnn_prepack_weights.argtypes = [ci, ci, fl, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp,
                                         ctypes.POINTER(vp)]
     lib.qnn_free_weights.argtypes = [vp]
@@ -185,6 +186,14 @@ def unpack(p, pixels, channels, store, nb):
     out = torch.empty((pixels, channels), dtype=torch.float32, device=p.device)
     check(load().qnn_unpack_f32(ptr(p), ptr(out), pixels, channels, store, nb, stream_ptr()),
           "qnn_unpack_f32")
+    return out
+
+
+def avgpool_packed(p, store, bits, N, H, W, C, size):
+    """AveragePooling2D(size) 'valid' of a packed NHWC tensor -> float32 (N, H//size, W//size, C)."""
+    out = torch.empty((N, H // size, W // size, C), dtype=torch.float32, device=p.device)
+    check(load().qnn_avgpool_packed_f32(ptr(p), store, bits, N, H, W, C, size, ptr(out), stream_ptr()),
+          "qnn_avgpool_packed_f32")
     return out
 
 

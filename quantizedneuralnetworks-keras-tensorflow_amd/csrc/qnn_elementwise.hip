@@ -224,7 +224,64 @@ __global__ __launch_bounds__(kBlock) void k_unpack(const uint32_t* __restrict__ 
     }
 }
 
+// AveragePooling2D(pool_size) 'valid' on a packed tensor (models/resnet.py:134 behind the last activation):
+// window sums of grid values are exact integers, so y = float(sum of codes) * 2^-(bits-1) / (size*size) has ONE
+// rounding (the division), exactly what tf.nn.avg_pool's float32 sum-then-divide gives on such values.
+// One lane per (output pixel, channel): the lanes of a wave read the same words (broadcast) of consecutive channels.
+template <int STORE>
+__global__ __launch_bounds__(kBlock) void k_avgpool_packed(const uint32_t* __restrict__ x, float* __restrict__ y,
+                                                           int N, int H, int W, int C, int cw, int size, float inv_m) {
+    constexpr int PW = (STORE == QNN_STORE_BIN) ? 32 : (STORE == QNN_STORE_I4) ? 8 : 4;
+    constexpr int BITS = 32 / PW;
+    const int Ho = H / size, Wo = W / size;
+    const size_t total = (size_t)N * Ho * Wo * C;
+    const float area = (float)(size * size);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+        const int c = (int)(i % C);
+        const size_t q = i / C;
+        const int ox = (int)(q % Wo);
+        const int oy = (int)((q / Wo) % Ho);
+        const size_t n = q / ((size_t)Wo * Ho);
+        const int sh = (c % PW) * BITS;
+        int acc = 0;
+        for (int dy = 0; dy < size; ++dy) {
+            const uint32_t* row = x + ((n * H + (size_t)oy * size + dy) * W + (size_t)ox * size) * cw + c / PW;
+            for (int dx = 0; dx < size; ++dx) {
+                const uint32_t word = row[(size_t)dx * cw];
+                if constexpr (STORE == QNN_STORE_BIN) acc += ((word >> sh) & 1u) ? 1 : -1;
+                else acc += (int)(word << (32 - BITS - sh)) >> (32 - BITS);
+            }
+        }
+        y[i] = __fdiv_rn(__fmul_rn((float)acc, inv_m), area);
+    }
+}
+
 }  // namespace
+
+extern "C" int qnn_avgpool_packed_f32(const void* x, int store, int bits, int N, int H, int W, int C, int size,
+                                      float* y, void* stream) {
+    QNN_REQUIRE(x && y, QNN_EINVAL, "qnn_avgpool_packed_f32: null pointer");
+    QNN_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && size > 0 && size <= H && size <= W, QNN_EINVAL,
+                "qnn_avgpool_packed_f32: shape (%d,%d,%d,%d) size %d", N, H, W, C, size);
+    QNN_REQUIRE(store == QNN_STORE_BIN || ((store == QNN_STORE_I4 || store == QNN_STORE_I8) && bits >= 1 && bits <= store),
+                QNN_EINVAL, "qnn_avgpool_packed_f32: store=%d bits=%d", store, bits);
+    const size_t total = (size_t)N * (H / size) * (W / size) * C;
+    if (total == 0) return QNN_OK;
+    const int cw = qnn_words(store, C);
+    const float inv_m = store == QNN_STORE_BIN ? 1.0f : 1.0f / (float)(1u << (bits - 1));
+    size_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 65535u) blocks = 65535u;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t* xu = (const uint32_t*)x;
+    if (store == QNN_STORE_BIN)
+        hipLaunchKernelGGL(k_avgpool_packed<QNN_STORE_BIN>, dim3((unsigned)blocks), dim3(kBlock), 0, s, xu, y, N, H, W, C, cw, size, inv_m);
+    else if (store == QNN_STORE_I4)
+        hipLaunchKernelGGL(k_avgpool_packed<QNN_STORE_I4>, dim3((unsigned)blocks), dim3(kBlock), 0, s, xu, y, N, H, W, C, cw, size, inv_m);
+    else
+        hipLaunchKernelGGL(k_avgpool_packed<QNN_STORE_I8>, dim3((unsigned)blocks), dim3(kBlock), 0, s, xu, y, N, H, W, C, cw, size, inv_m);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
 
 // ---------------------------------------------------------------------------
 extern "C" int qnn_binary_tanh_f32(const float* x, float* y, size_t n, void* stream) {

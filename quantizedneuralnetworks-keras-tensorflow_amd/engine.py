@@ -457,8 +457,8 @@ class ResidualFusedModel:
             op = self.spec[ci]
             if op["op"] in ("conv", "dense") and _wstore(op) is not None:
                 joins.append(_join_store(bits, _wstore(op)))
-            elif op["op"] in ("add", "flatten"):
-                continue
+            elif op["op"] in ("add", "flatten", "avgpool"):
+                continue                 # these read packed codes directly (avgpool: qnn_avgpool_packed_f32)
             else:
                 return None
         if not joins:
@@ -628,10 +628,15 @@ class ResidualFusedModel:
                 N, H, W, C = t.shape
                 out = t[:, :H // s_ * s_, :W // s_ * s_, :].reshape(N, H // s_, s_, W // s_, s_, C).amax(dim=(2, 4))
             elif kind == "avgpool":
-                t = f32(self.srcs[i][0]); s_ = op.get("size", 8)
-                N, H, W, C = t.shape
-                win = t[:, :H // s_ * s_, :W // s_ * s_, :].reshape(N, H // s_, s_, W // s_, s_, C)
-                out = win.double().sum(dim=(2, 4)).float() / F32(s_ * s_)
+                src = ev(self.srcs[i][0]); s_ = op.get("size", 8)
+                if isinstance(src, _Packed):     # window sums on the codes: no float32 copy of the activation
+                    N, H, W, C = src.shape
+                    out = _abi.avgpool_packed(src.t, src.store, src.bits, N, H, W, C, s_)
+                else:
+                    t = src
+                    N, H, W, C = t.shape
+                    win = t[:, :H // s_ * s_, :W // s_ * s_, :].reshape(N, H // s_, s_, W // s_, s_, C)
+                    out = win.double().sum(dim=(2, 4)).float() / F32(s_ * s_)
             elif kind == "zeropad":
                 p_ = op["pad"]
                 out = torch.nn.functional.pad(f32(self.srcs[i][0]), (0, 0, p_, p_, p_, p_))

@@ -160,7 +160,7 @@ def test_fused_chain_grouping_and_residual_planning():
     m = engine.ResidualFusedModel(rspec, device="cpu")
     acts = [n for n, i in m.prod.items() if rspec[i]["op"] == "act"]
     stores = {m._act_out_store(n, 4) for n in acts}
-    assert stores == {_abi.STORE_I4, None}                  # the last activation feeds the avg-pool (float32)
+    assert stores == {_abi.STORE_I4}                        # every activation stays packed: the avg-pool reads the codes too
     adds = [i for i, op in enumerate(rspec) if op["op"] == "add"]
     assert len(adds) == 3 and all(len(m.srcs[i]) == 2 for i in adds)
     bcf = nets.Config(network_type="full-bnn", architecture="RESNET", nres=1, dim=32)

@@ -656,7 +656,10 @@ def test_residual_fused_model(nt, wb, ab, nres):
             # (the first 32-channel block starts with a stride-2 conv; its second conv merges the
             # float32 projection shortcut, which the kernel reads directly)
             assert m.kernel_log.count("strip_i4_c32") >= 2 * nres - 1, m.kernel_log
-            assert any(k.startswith("mfma_i4_areg") for k in m.kernel_log), m.kernel_log
+            # 64-channel stage: residual merges on the strip kernel, plain conv -> BN -> act layers on the LDS-weight one
+            assert "strip_i4_c64" in m.kernel_log, m.kernel_log
+            if nres > 1:
+                assert any(k.startswith("mfma_i4_areg") for k in m.kernel_log), m.kernel_log
 
 
 def test_residual_fused_model_at_imagenet_geometry():
@@ -702,6 +705,21 @@ def test_config5_imagenet224_resnet_nres10_at_spec():
     # the softmax output through the general interpreter agrees too
     probs = host(engine.GraphModel(spec)(dev(x)))
     np.testing.assert_allclose(probs, O.softmax(want), atol=1e-6)
+
+
+@pytest.mark.parametrize("store,bits,shape,size", [(_abi.STORE_I4, 4, (3, 56, 56, 64), 8), (_abi.STORE_I4, 2, (2, 9, 10, 24), 3),
+                                                   (_abi.STORE_I8, 8, (2, 16, 16, 12), 8), (_abi.STORE_BIN, 1, (2, 8, 8, 64), 8),
+                                                   (_abi.STORE_I4, 4, (1, 8, 8, 16), 8)])
+def test_average_pool_on_packed_codes(store, bits, shape, size):
+    """AveragePooling2D behind the last activation (resnet.py:134) reads the packed codes: exact window sums."""
+    rng = np.random.default_rng(bits + shape[1])
+    N, H, W, C = shape
+    act = BIN_ACT if bits == 1 else Q(bits)
+    x = O.run_spec([act], rng.standard_normal(shape).astype(F32))
+    fn, b = engine._act_code(act)
+    p = _abi.pack(dev(x), C, _abi.FN_GRID, b, store)
+    got = host(_abi.avgpool_packed(p, store, b, N, H, W, C, size))
+    np.testing.assert_array_equal(got, O.avgpool2d(x, size))
 
 
 @pytest.mark.parametrize("code,wb,ab", [("44", 4, 4), ("bb", None, None)])
