@@ -154,11 +154,16 @@ def step_bytes(abi, st, N, H, W):
 
 
 def time_launch(torch, launch, reps=20, lead=4, rounds=3):
-    """Average duration of one launch, HIP events on the launching stream.  The first event is recorded
-    BEHIND a few queued launches, so the host's launch latency is not inside the measured interval:
-    (ev1 - ev0) / reps is the kernel's own duration, the figure rocprofv3's kernel trace reports."""
-    out, times = None, []
-    for _ in range(rounds):              # the median of a few rounds: the first one can still see the clock ramp
+    """Duration of one launch, HIP events on the launching stream, two ways:
+      back-to-back   (ev1 - ev0) / reps around `reps` queued launches; the first event is recorded BEHIND a few queued
+                     launches so the host's launch latency is not inside the interval.  Includes the kernel boundary
+                     (with 33 MB of dirty output the write-back between two launches is ~6 us);
+      per launch     an event pair around every launch, median of the intervals: the boundary falls between two
+                     intervals.  Only meaningful while the host stays ahead of the GPU (long kernels).
+    The smaller of the two is the kernel's own duration, the figure rocprofv3's kernel trace reports; the median over a
+    few rounds is taken because the first round can still see the clock ramp.  Returns (ms, back_to_back_ms, output)."""
+    out, agg, pair = None, [], []
+    for _ in range(rounds):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         for _ in range(lead):
@@ -168,8 +173,19 @@ def time_launch(torch, launch, reps=20, lead=4, rounds=3):
             out = launch()
         ev1.record()
         torch.cuda.synchronize()
-        times.append(ev0.elapsed_time(ev1) / reps)
-    return sorted(times)[len(times) // 2], out
+        agg.append(ev0.elapsed_time(ev1) / reps)
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        for _ in range(lead):
+            out = launch()
+        for i in range(reps):
+            starts[i].record()
+            out = launch()
+            ends[i].record()
+        torch.cuda.synchronize()
+        pair.append(sorted(a.elapsed_time(b) for a, b in zip(starts, ends))[reps // 2])
+    b2b = sorted(agg)[len(agg) // 2]
+    return min(b2b, sorted(pair)[len(pair) // 2]), b2b, out
 
 
 def layer_roof_ms(k):
@@ -271,9 +287,9 @@ def main_rank(args):
                 return abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
                                  st["fn"], st["act_bits"], st["out_store"])
 
-            ms, outs = time_launch(torch, launch)
+            ms, b2b, outs = time_launch(torch, launch)
             kh, kw, cin, cout = st["w"].shape
-            per_kernel.append(dict(kernel=abi.last_kernel(), ms=ms, bytes=nbytes, launches=1,
+            per_kernel.append(dict(kernel=abi.last_kernel(), ms=ms, b2b_ms=b2b, bytes=nbytes, launches=1,
                                    pipe="f32" if st["x_store"] == abi.STORE_F32 else "i8",
                                    macs=N * (ho * wo * st["pool"] ** 2 if st["kind"] == "conv" else 1)
                                    * kh * kw * cin * cout))
@@ -286,7 +302,7 @@ def main_rank(args):
         torch.cuda.synchronize()
         groups = {}
         for c in model.capture:
-            ms, _ = time_launch(torch, c["launch"], reps=8, lead=2, rounds=1)
+            ms, _, _ = time_launch(torch, c["launch"], reps=8, lead=2, rounds=1)
             g = groups.setdefault((c["kernel"], c["shape"]), dict(kernel=c["kernel"], shape=c["shape"], ms_total=0.0,
                                                                   launches=0, bytes=c["bytes"], macs=c["macs"],
                                                                   pipe=c["pipe"]))
@@ -415,6 +431,7 @@ def main_rank(args):
         traffic, rocprof_name = load_traffic(d["kernel"])
         common = {"kernel": d["kernel"], "rocprof_kernel": rocprof_name, "layer_index": dom,
                   "launches_per_step": d["launches"], "avg_launch_ms": d["ms"],
+                  "back_to_back_launch_ms": d.get("b2b_ms"),
                   "algorithmic_bytes_per_launch": d["bytes"], "traffic": traffic}
         if d["kernel"].startswith("mfma_") and 2.0 * d["macs"] / (MFMA_PEAK_TFLOPS["f32" if d["pipe"] == "f32" else "i8"] * 1e12) \
                 >= d["bytes"] / (HBM_PEAK_GBS * 1e9):

@@ -39,35 +39,55 @@ def _trick(x, c, s):
 
 
 def forward(spec, x):
-    """x: float32 NHWC torch CPU tensor (sequential specs only)."""
+    """x: float32 NHWC torch CPU tensor.  Sequential specs (models/vgg.py) and residual ones (models/resnet.py:
+    ops name their inputs with `src` / `a`, `b` and their output with `dst`)."""
+    env = {"input": x}
     cur = x
-    for op in spec:
+    for i, op in enumerate(spec):
         k = op["op"]
+        src = env[op["src"]] if "src" in op else cur
         if k == "conv":
             w = op["_w"]
             wq = _binary_tanh(w) if op["kind"] == "binary" else _quantize(w, op["nb"])
             c_in, s_in, c_out, s_out = op["_trick"]
-            xin = _trick(cur, c_in, s_in)
-            y = F.conv2d(xin.permute(0, 3, 1, 2), wq.permute(3, 2, 0, 1), None,
-                         stride=op.get("strides", (1, 1)), padding=1 if w.shape[0] == 3 else 0)
+            xin = _trick(src, c_in, s_in)
+            st = tuple(op.get("strides", (1, 1)))
+            xin = xin.permute(0, 3, 1, 2)
+            if w.shape[0] == 3:                      # TF 'SAME': 1/1 at stride 1, 0/1 at stride 2 on even sizes
+                pt, pb = O.same_padding(xin.shape[2], 3, st[0])[1:]
+                pl, pr = O.same_padding(xin.shape[3], 3, st[1])[1:]
+                xin = F.pad(xin, (pl, pr, pt, pb))
+            y = F.conv2d(xin, wq.permute(3, 2, 0, 1), None, stride=st)
             y = _trick(y.permute(0, 2, 3, 1), c_out, s_out)
             cur = y + op["_b"] if op.get("bias") is not None else y
         elif k == "dense":
             w = op["_w"]
             wq = _binary_tanh(w) if op["kind"] == "binary" else _quantize(w, op["nb"])
-            cur = cur @ wq
+            cur = src @ wq
             if op.get("bias") is not None:
                 cur = cur + op["_b"]
         elif k == "bn":
-            cur = cur * op["_inv"] + op["_shift"]
+            cur = src * op["_inv"] + op["_shift"]
         elif k == "act":
-            cur = _binary_tanh(cur) if op["fn"] == "binary_tanh" else _quantize(cur, op["nb"])
+            cur = _binary_tanh(src) if op["fn"] == "binary_tanh" else _quantize(src, op["nb"])
         elif k == "maxpool":
-            cur = F.max_pool2d(cur.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            cur = F.max_pool2d(src.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        elif k == "avgpool":
+            cur = F.avg_pool2d(src.permute(0, 3, 1, 2), op.get("size", 8)).permute(0, 2, 3, 1)
         elif k == "flatten":
-            cur = cur.reshape(cur.shape[0], -1)
+            cur = src.reshape(src.shape[0], -1)
+        elif k == "add":
+            cur = env[op["a"]] + env[op["b"]]
+        elif k == "scale":
+            cur = src * float(op["value"])
+        elif k == "softmax":
+            cur = torch.softmax(src, dim=-1)
+        elif k == "zeropad":
+            p = op["pad"]
+            cur = F.pad(src, (0, 0, p, p, p, p))
         else:
             raise ValueError(k)
+        env[op.get("dst", "t%d" % i)] = cur
     return cur
 
 
@@ -109,10 +129,12 @@ def _usable_cores():
     return max(1, min(n, int(os.environ.get("QNN_CPU_BASELINE_THREADS", "32"))))
 
 
-def run(cf, spec, seconds=12.0, batch=256):
+def run(cf, spec, seconds=12.0, batch=None):
     cores = _usable_cores()
     torch.set_num_threads(cores)
     prepared = prepare(spec)
+    if batch is None:                              # ~a second of work per call on a 16-core host
+        batch = 256 if cf.dim <= 64 else 4
     rng = np.random.default_rng(1)
     x = torch.as_tensor((rng.integers(0, 256, (batch, cf.dim, cf.dim, cf.channels)).astype(np.float32)
                          / np.float32(255)))

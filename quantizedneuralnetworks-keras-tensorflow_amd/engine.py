@@ -516,7 +516,8 @@ class ResidualFusedModel:
                 if res is not None:
                     b += nbytes(rkw["res_store"], N * Ho * Wo, cout)
                 self.capture.append(dict(kernel=_abi.last_kernel(), launch=lambda: launch()[0],
-                                         shape=(N, H, W, C, cout, kh, tuple(op.get("strides", (1, 1)))[0]),
+                                         shape=(N, H, W, C, cout, kh, tuple(op.get("strides", (1, 1)))[0],
+                                                "res_" + ("none" if res is None else "packed" if isinstance(res, _Packed) else "f32")),
                                          bytes=b, macs=N * Ho * Wo * kh * kw * C * cout,
                                          pipe="f32" if xs == _abi.STORE_F32 else "i8"))
             if out_store == _abi.STORE_F32:
