@@ -106,11 +106,17 @@ const char* qnn_last_error(void);
  * (XNOR+popcount / v_dot8 / v_dot4), 2 = prefer the int8 MFMA implicit GEMM.
  * Process-wide; results are bit-identical across families. */
 int         qnn_set_conv_impl(int impl);
-/* Kernel-selection switches for A/B measurements and tests; every setting gives bit-identical results.
+/* Kernel-selection switches for A/B measurements and tests; "strip" / "strip64" give bit-identical results under
+ * every setting, "first_fixed" does NOT (see below).
  *   "strip" (default 1): row-walking kernel for the 3x3 stride-1 int4 layers with 16 / 32 channels;
  *                        0 = the tile kernel (k_conv_mfma_small) takes them.
  *   "strip64" (default -1): the same kernel for 64-channel layers: -1 = only where a residual is merged (the LDS-weight kernel
- *                        is faster without one), 0 never, 1 always. */
+ *                        is faster without one), 0 never, 1 always.
+ *   "first_fixed" (default 0): 1 = float-input 3x3 layers with 3 channels, 64 filters of <= 4 bits and inputs in [0, 1]
+ *                        run in fixed point (inputs rounded to 2^-23, exact int32 sums on the int8 matrix pipe, one
+ *                        rounding): within 27 * 2^-24 + half an ulp of the REAL-number convolution, hence inside the
+ *                        1e-5 contract, but not the float32 FMA chain of the default kernel -- activation codes whose
+ *                        pre-activation sits that close to a rounding threshold can differ from the oracle's. */
 int         qnn_set_option(const char* key, int value);
 
 /* ---- elementwise activation clips on float32 tensors --------------------- */

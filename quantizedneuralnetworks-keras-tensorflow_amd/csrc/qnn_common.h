@@ -58,7 +58,9 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
 int qnn_conv_impl_pref();
 int qnn_try_launch_stem(const ConvGeom& g, const EpiArgs& e, const void* x, const float* wq, void* y, hipStream_t s);
 int qnn_option(int which);
-enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_COUNT = 4 };
+int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
+                               hipStream_t s);
+enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_FIRST_FIXED = 2, QNN_OPT_COUNT = 4 };
 
 // ---- division by a launch-constant via multiply-high (dividends < 2^31) ----------
 struct FastDiv {

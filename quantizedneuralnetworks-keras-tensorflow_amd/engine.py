@@ -196,6 +196,7 @@ class FusedModel:
         x = _abi.require_cuda(x, "FusedModel.forward")
         N, H, W, _ = x.shape
         cur = x
+        log = getattr(self, "kernel_log", None)      # tests: set to a list to record the kernel of every layer
         for st in self.steps:
             if st["kind"] == "conv":
                 cur, H, W = _abi.conv2d(st["w"], cur, st["x_store"], st["x_bits"], N, H, W, st["inv"],
@@ -203,6 +204,8 @@ class FusedModel:
             else:
                 cur = _abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
                                  st["fn"], st["act_bits"], st["out_store"])
+            if log is not None:
+                log.append(_abi.last_kernel())
             if st["softmax"]:
                 cur = torch.softmax(cur, dim=-1)
         return cur
