@@ -18,6 +18,10 @@
 // ds_read_b32 per (tile, digit).  In the C/D layout a lane holds the four positions of ONE window for one filter: pooling
 // is an in-lane max on the combined integers (filters of channels with negative BN scale are negated, as in the exact
 // kernel), and the epilogue / nibble transpose / packed store are the exact kernel's.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "qnn_mfma_common.h"
 
 namespace {
@@ -33,11 +37,12 @@ __device__ __forceinline__ uint32_t to_digits(float x) {
 }
 constexpr int kDigitBias = 128 * (1 + 256 + 65536);              // sum_j 128 * 2^(8j)
 
-template <int OUT, int POOL>      // (QNN_STORE_I4, 2): the fused pipeline;  (QNN_STORE_F32, 1): the raw layer (tests)
+// (QNN_STORE_I4, 2, BIN): the fused pipeline, quantized_tanh / binary_tanh codes;  (QNN_STORE_F32, 1, false): the raw layer
+template <int OUT, int POOL, bool BIN>
 __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs e, const float* __restrict__ x,
                                                               const float* __restrict__ wq, void* __restrict__ y,
                                                               int ntasks, int spr, FastDiv fd_spr, int nch, FastDiv fd_nch,
-                                                              int rc, uint32_t img_x, float wscale, float vscale) {
+                                                              int rc, uint32_t img_x, float wscale, float vscale, float rvscale) {
     extern __shared__ __attribute__((aligned(16))) char smem_fx[];
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, kq = lane >> 4;
@@ -45,47 +50,68 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs
     const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem_fx) + wave * kWaveLds;
     uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
+    uint4* tab = reinterpret_cast<uint4*>(smem_fx + 4 * kWaveLds * 4);      // [filter block][lane][2]
     for (int i = lane; i < kWaveLds; i += 64) lds[i] = 0;        // the 4th byte of every pixel stays zero
 
-    // ---- filters: B operand of block nt = filter nt*16 + r, k-block kq = tap row dy ----
-    const bool binary = e.fn == QNN_FN_BINARY_TANH;
-    const float mfold = (OUT == QNN_STORE_I4 && !binary) ? e.act_m : 1.0f;
-    v4i bw[4];
-    int c0[4];
-    float nb[4], ninv[4], nshift[4];
-    LaneEpi ke;
-    lane_epi_init<QNN_STORE_I4>(ke, e, r, r);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int c = nt * 16 + r;
+    // ---- filters: B operand of block nt = filter nt*16 + r, k-block kq = tap row dy.  Wave nt prepares block nt for the
+    // whole workgroup (the scalar setup is ~250 instructions; every wave doing all four blocks cost 10 % of the launch) ----
+    const float mfold = (OUT == QNN_STORE_I4 && !BIN) ? e.act_m : 1.0f;
+    {
+        const int c = wave * 16 + r;
         const float bias = e.bias ? e.bias[c] : 0.0f;
         const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
         const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
         const bool flip = POOL == 2 && inv < 0.0f;               // pool with max only: negate the filter, fold the sign
-        int sum = 0;
-        uint32_t wd[4] = {0u, 0u, 0u, 0u};
-        for (int k = 0; k < 27; ++k) {
-            int code = (int)rintf(__fmul_rn(wq[(size_t)c * 27 + k], wscale));
+        // this lane's tap row (k-block 3 is padding: it loads row 2 and keeps zeros)
+        const float* wrow = wq + (size_t)c * 27 + (kq < 3 ? kq : 2) * 9;
+        int part = 0;
+        uint32_t wd[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int code = (int)rintf(__fmul_rn(wrow[i], wscale));
             if (flip) code = -code;
-            sum += code;
-            const int dy = k / 9, dx = (k % 9) / 3, ch = k % 3;
-            if (dy == kq) wd[dx] |= (uint32_t)(code & 0xFF) << (8 * ch);
+            if (kq == 3) code = 0;
+            part += code;
+            wd[i / 3] |= (uint32_t)(code & 0xFF) << (8 * (i % 3));
         }
-        bw[nt] = kq < 3 ? __builtin_bit_cast(v4i, make_uint4(wd[0], wd[1], wd[2], 0u)) : v4i{0, 0, 0, 0};
-        c0[nt] = sum * kDigitBias;                               // |.| <= 27 * 8 * 8421504 < 2^31
-        nb[nt] = __fdiv_rn(flip ? -bias : bias, vscale);
-        ninv[nt] = __fmul_rn(__fmul_rn(flip ? -inv : inv, vscale), mfold);
-        nshift[nt] = __fmul_rn(shift, mfold);
+        part += __shfl_xor(part, 16);                            // sum of the 27 codes of filter c: the three tap rows
+        part += __shfl_xor(part, 32);                            // sit in the lanes r, r + 16, r + 32
+        const float nb_ = __fmul_rn(flip ? -bias : bias, rvscale);           // bias / vscale (a power of two)
+        const float ninv_ = __fmul_rn(__fmul_rn(flip ? -inv : inv, vscale), mfold);
+        const float nshift_ = __fmul_rn(shift, mfold);
+        tab[(wave * 64 + lane) * 2] = make_uint4(wd[0], wd[1], wd[2], (uint32_t)(part * kDigitBias));   // |.| < 2^31
+        tab[(wave * 64 + lane) * 2 + 1] = make_uint4(__float_as_uint(nb_), __float_as_uint(ninv_), __float_as_uint(nshift_), 0u);
     }
-    // ---- operand addresses (dword index inside a digit plane): position m = r: window w = r >> 2, (py, px) = bits of r ----
+    __syncthreads();
+    v4i bw[4];
+    int c0[4];
+    float nb[4], ninv[4], nshift[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const uint4 t0 = tab[(nt * 64 + lane) * 2], t1 = tab[(nt * 64 + lane) * 2 + 1];
+        bw[nt] = __builtin_bit_cast(v4i, make_uint4(t0.x, t0.y, t0.z, 0u));
+        c0[nt] = (int)t0.w;
+        nb[nt] = __uint_as_float(t1.x); ninv[nt] = __uint_as_float(t1.y); nshift[nt] = __uint_as_float(t1.z);
+    }
+    LaneEpi ke;
+    lane_epi_init<QNN_STORE_I4>(ke, e, r, r);
+    constexpr int kMagicBits = 0x4B400008;                       // 1.5 * 2^23 + 8: see qnn_mfma_strip.hip
+    const float magic = __int_as_float(kMagicBits);
+    const int code_lo = kMagicBits - (int)e.act_m, code_hi = kMagicBits + (int)e.act_m - 1;
+    // ---- operand addresses (dword index inside a digit plane): position m = r: window w = r >> 2, (py, px) = bits of r.
+    // A step works on conv rows yy0 = 2*rp and yy0 + 1; with rp0 even (the launcher makes every chunk start on an even
+    // pair) the ring slot of input row yy0 + py + dy - 1 is (2*(rp & 1) + py + kq) & 3: two lane constants ----
     const int py = (r >> 1) & 1, px = r & 1, w = r >> 2;
-    const int acol = 2 * w + px;                                 // + 8*t + dx
-    // ---- staging: two input rows = 108 floats per step, elements lane and lane + 64 ----
+    const int ab0 = ((py + kq) & 3) * kRowPitch + 2 * w + px;            // + 8*t, + dx by the 4-dword read
+    const int ab1 = ((2 + py + kq) & 3) * kRowPitch + 2 * w + px;
+    // ---- staging: two input rows = 108 floats per step, elements lane and lane + 64 (lanes >= 44: a dummy pixel) ----
     const int e0row = lane >= 54 ? 1 : 0, e0rem = lane - 54 * e0row;
     const int e0px = e0rem / 3, e0ch = e0rem - 3 * e0px;
     const bool e1ok = lane < 44;
     const int e1rem = e1ok ? lane + 10 : 0;
     const int e1px = e1rem / 3, e1ch = e1rem - 3 * e1px;
+    const int st0 = e0row * (kRowPitch * 4) + e0px * 4 + e0ch;           // + slot * 160 (+ plane * 640)
+    const int st1 = e1ok ? kRowPitch * 4 + e1px * 4 + e1ch : kRowPitch * 4 + 30 * 4;     // pixel 30 of a row is never read
     const int rowf = g.W * 3 * 4;                                // bytes per input row
 
     for (int task = wid; task < ntasks; task += nw) {
@@ -93,7 +119,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs
         const int chunk = task - (int)rest * nch;
         const int n = (int)qnn_div(rest, fd_spr);
         const int xs = ((int)rest - n * spr) * 16;
-        const int rp0 = chunk * rc, rp1 = min(rp0 + rc, g.H / 2);
+        const int rp0 = chunk * rc, rp1 = min(rp0 + rc, g.H / 2);        // rc is even or nch == 1: rp0 is even
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
             (uint8_t*)const_cast<float*>(x) + (size_t)n * img_x, 0, (int)img_x, 0x00020000);
         // byte offsets of the two staged elements for input row `row` (added below); columns outside the image and, through
@@ -101,90 +127,119 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs
         const int c0col = xs - 1 + e0px, c1col = xs - 1 + e1px;
         const int v0 = (c0col >= 0 && c0col < g.W) ? (c0col * 3 + e0ch) * 4 + e0row * rowf : (int)0x80000000;
         const int v1 = (e1ok && c1col >= 0 && c1col < g.W) ? (c1col * 3 + e1ch) * 4 + rowf : (int)0x80000000;
-        float f0, f1;
-        auto stage_load = [&](int row) {                         // rows `row`, `row + 1`
+        auto stage_load = [&](int row, float& f0, float& f1) {   // rows `row`, `row + 1`
             const int so = row * rowf;                           // may be negative: the sum wraps out of range
             f0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, v0 + so, 0, 0));
             f1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, v1 + so, 0, 0));
         };
-        auto stage_write = [&](int row) {
-            const int s0 = ((row + 1 + e0row) & 3) * (kRowPitch * 4), s1 = ((row + 2) & 3) * (kRowPitch * 4);
-            const uint32_t d0 = to_digits(f0);
-            const int b0 = s0 + e0px * 4 + e0ch;
-            ldsb[b0] = (uint8_t)d0; ldsb[b0 + kPlane * 4] = (uint8_t)(d0 >> 8); ldsb[b0 + 2 * kPlane * 4] = (uint8_t)(d0 >> 16);
-            if (e1ok) {
-                const uint32_t d1 = to_digits(f1);
-                const int b1 = s1 + e1px * 4 + e1ch;
-                ldsb[b1] = (uint8_t)d1; ldsb[b1 + kPlane * 4] = (uint8_t)(d1 >> 8); ldsb[b1 + 2 * kPlane * 4] = (uint8_t)(d1 >> 16);
-            }
+        // rows `row`, `row + 1` into the ring slots SLOT, SLOT + 1
+        auto stage_write = [&](auto slotc, float f0, float f1) {
+            constexpr int SB = decltype(slotc)::value * (kRowPitch * 4);
+            const uint32_t d0 = to_digits(f0), d1 = to_digits(f1);
+            ldsb[st0 + SB] = (uint8_t)d0; ldsb[st0 + SB + kPlane * 4] = (uint8_t)(d0 >> 8);
+            ldsb[st0 + SB + 2 * kPlane * 4] = (uint8_t)(d0 >> 16);
+            ldsb[st1 + SB] = (uint8_t)d1; ldsb[st1 + SB + kPlane * 4] = (uint8_t)(d1 >> 8);
+            ldsb[st1 + SB + 2 * kPlane * 4] = (uint8_t)(d1 >> 16);
         };
         const int yy_first = 2 * rp0;
-        stage_load(yy_first - 1);
-        stage_write(yy_first - 1);
-        stage_load(yy_first + 1);
-        for (int rp = rp0; rp < rp1; ++rp) {
+        float fa0, fa1, fb0, fb1, fc0, fc1;
+        stage_load(yy_first - 1, fa0, fa1);
+        stage_load(yy_first + 1, fb0, fb1);
+        stage_load(yy_first + 3, fc0, fc1);
+        stage_write(std::integral_constant<int, 0>{}, fa0, fa1);         // rows yy_first - 1, yy_first: slots 0, 1
+
+        auto step = [&](auto parc, int rp) {
+            constexpr int PAR = decltype(parc)::value;           // rp & 1
             const int yy0 = 2 * rp;
-            stage_write(yy0 + 1);                                // rows yy0+1, yy0+2 complete the four rows of this step
-            stage_load(yy0 + 3);                                 // next step's rows, in flight during the matrix phase
-            // input row of this lane's operand: yy0 + py + dy - 1 -> ring slot (yy0 + py + kq) & 3
-            const int abase = ((yy0 + py + kq) & 3) * kRowPitch + acol;
-            int T[2][4];                                         // [tile][filter block]: pooled sums
+            // rows yy0+1, yy0+2 complete the four rows of this step: slots (yy0 + 2) & 3 and the next
+            stage_write(std::integral_constant<int, PAR ? 0 : 2>{}, fb0, fb1);
+            fb0 = fc0; fb1 = fc1;
+            stage_load(yy0 + 5, fc0, fc1);                       // two steps ahead: in flight during two matrix phases
+            const uint32_t* abase = lds + (PAR ? ab1 : ab0);
+            // 8 groups (tile t = g >> 2, filter block nt = g & 3) of three digit passes; the passes of group g + 1 are
+            // issued before group g is combined, so the combine never waits for the matrix pipe
+            v4i A[2][3];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                v4i A[3];
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const uint32_t* p = lds + j * kPlane + abase + 8 * t;
-                    A[j] = __builtin_bit_cast(v4i, make_uint4(p[0], p[1], p[2], 0u));   // k-block 3: times zero filters
+                    const uint32_t* p = abase + j * kPlane + 8 * t;
+                    // the 4th dword (the pixel after the three taps) meets zero filter bytes
+                    A[t][j] = __builtin_bit_cast(v4i, make_uint4(p[0], p[1], p[2], p[3]));
                 }
+            v4i acc[2][3];
+            int T[8];
+            auto issue = [&](int gq, v4i (&a)[3]) {
+                const v4i z = {0, 0, 0, 0};
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const v4i z = {0, 0, 0, 0};
-                    const v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], bw[nt], z, 0, 0, 0);
-                    const v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], bw[nt], z, 0, 0, 0);
-                    const v4i a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], bw[nt], z, 0, 0, 0);
-                    int raw[4];
+                for (int j = 0; j < 3; ++j) a[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[gq >> 2][j], bw[gq & 3], z, 0, 0, 0);
+            };
+            auto combine = [&](int gq, const v4i (&a)[3]) {
+                int raw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // two v_lshl_add_u32; the empty asm only stops the reassociation into two shifts and an add3
+                    // (real instructions stay visible to the compiler's MFMA -> VALU hazard handling)
+                    int hi = (int)(((uint32_t)a[2][i] << 8) + (uint32_t)a[1][i]);
+                    asm("" : "+v"(hi));
+                    raw[i] = (int)(((uint32_t)hi << 8) + (uint32_t)a[0][i]);
+                }
+                const int t = gq >> 2, nt = gq & 3;
+                if constexpr (POOL == 2) {
+                    T[gq] = max(max(raw[0], raw[1]), max(raw[2], raw[3])) + c0[nt];
+                } else {
+                    // raw layer output (tests): position i of window kq -> conv pixel (yy0 + (i >> 1), xs + 8t + 2kq + (i & 1))
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        // two v_lshl_add_u32; the empty asm only stops the reassociation into two shifts and an add3
-                        // (real instructions stay visible to the compiler's MFMA -> VALU hazard handling)
-                        int hi = (int)(((uint32_t)a2[i] << 8) + (uint32_t)a1[i]);
-                        asm("" : "+v"(hi));
-                        raw[i] = (int)(((uint32_t)hi << 8) + (uint32_t)a0[i]);
-                    }
-                    if constexpr (POOL == 2) {
-                        T[t][nt] = max(max(raw[0], raw[1]), max(raw[2], raw[3])) + c0[nt];
-                    } else {
-                        // raw layer output (tests): position i of window kq -> conv pixel (yy0 + (i >> 1), xs + 8t + 2kq + (i & 1))
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int c = nt * 16 + r;
-                            float v = __fmul_rn((float)(raw[i] + c0[nt]), vscale);
-                            v = qnn_epi_value(v, c, e);
-                            if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
-                            else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
-                            const long q = ((long)n * g.H + yy0 + (i >> 1)) * g.W + xs + 8 * t + 2 * kq + (i & 1);
-                            reinterpret_cast<float*>(y)[q * g.cout + c] = v;
-                        }
+                        const int c = nt * 16 + r;
+                        float v = __fmul_rn((float)(raw[i] + c0[nt]), vscale);
+                        v = qnn_epi_value(v, c, e);
+                        if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
+                        else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
+                        const long q = ((long)n * g.H + yy0 + (i >> 1)) * g.W + xs + 8 * t + 2 * kq + (i & 1);
+                        reinterpret_cast<float*>(y)[q * g.cout + c] = v;
                     }
                 }
+            };
+            issue(0, acc[0]);
+#pragma unroll
+            for (int gq = 0; gq < 8; ++gq) {
+                if (gq + 1 < 8) issue(gq + 1, acc[(gq + 1) & 1]);
+                combine(gq, acc[gq & 1]);
             }
             if constexpr (OUT == QNN_STORE_I4) {
-                // lane (filter r, window kq): 8 values j = 4*t + nt -> after the transpose lane (r & 7) holds the word of
+                // lane (filter r, window kq): value j = 4*t + nt -> after the transpose lane (r & 7) holds the word of
                 // value j = r & 7: pooled pixel (xs/2 + kq + 4*(j >> 2)), channels (j & 3)*16 + (r & 8) .. +7
-                float tv[8];
+                int cb[8];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int j = 0; j < 8; ++j) {
+                    const float u = __fadd_rn(__fmul_rn(__fadd_rn((float)T[j], nb[j & 3]), ninv[j & 3]), nshift[j & 3]);
+                    if constexpr (BIN) {
+                        cb[j] = u > 0x1p-24f ? kMagicBits + 1 : kMagicBits - 1;
+                    } else {
+                        // rint + clamp in one add and one integer median (the low bits of u + magic are rint(u) + 8)
+                        const int bits = __float_as_int(__fadd_rn(u, magic));
+                        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cb[j]) : "v"(bits), "v"(code_lo), "v"(code_hi));
+                    }
+                }
+                // cb[j] = kMagicBits - 8 + (code + 8): the sum of the shifted words minus the shifted constants (mod 2^32)
+                // leaves the eight offset nibbles
+                uint32_t P = (uint32_t)cb[0];
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        tv[t * 4 + nt] = __fadd_rn(__fmul_rn(__fadd_rn((float)T[t][nt], nb[nt]), ninv[nt]), nshift[nt]);
-                const uint32_t P = pack_scaled<4, 8>(tv, e.act_m, binary);
+                for (int j = 1; j < 8; ++j) P += (uint32_t)cb[j] << (4 * j);
+                P -= (uint32_t)(kMagicBits - 8) * 0x11111111u;
                 const uint32_t Wd = transpose_nib8(P, ke) ^ 0x88888888u;
                 const int j = r & 7;
                 const long q = ((long)n * g.Hp + rp) * g.Wp + (xs >> 1) + kq + 4 * (j >> 2);
                 reinterpret_cast<uint32_t*>(y)[q * e.ocw + (j & 3) * 2 + (r >> 3)] = Wd;
             }
+        };
+        int rp = rp0;
+        for (; rp + 2 <= rp1; rp += 2) {
+            step(std::integral_constant<int, 0>{}, rp);
+            step(std::integral_constant<int, 1>{}, rp + 1);
         }
+        if (rp < rp1) step(std::integral_constant<int, 0>{}, rp);
     }
 }
 
@@ -210,11 +265,12 @@ int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* 
     const double img_x = (double)g.H * g.W * 3 * 4.0;
     if (img_x >= 1.0e9 || (double)g.N * g.Hp * g.Wp * 8.0 >= 2.0e9 * 4) return 1;
     const int hp2 = g.H / 2;
-    const int blocks_cap = 256 * 4;
+    static const int bpc = getenv("QNN_FIXED_BPC") ? atoi(getenv("QNN_FIXED_BPC")) : 4;   // A/B switch, read once
+    const int blocks_cap = 256 * (bpc >= 1 && bpc <= 5 ? bpc : 4);
     const long nwaves = (long)blocks_cap * 4;
     int best_rc = hp2, best_nch = 1;
     double best_cost = 1e300;
-    for (int rc = 1; rc <= hp2; ++rc) {
+    for (int rc = 2; rc <= hp2 + 1; rc += 2) {              // even: every chunk starts on an even row pair
         const int nch = (hp2 + rc - 1) / rc;
         const long rounds = ((long)g.N * spr * nch + nwaves - 1) / nwaves;
         const double cost = (double)rounds * (rc + 1.5);
@@ -225,14 +281,14 @@ int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* 
     long blocks = (ntasks_l + 3) / 4;
     if (blocks > blocks_cap) blocks = blocks_cap;
     const dim3 grid((unsigned)blocks), block(256);
-    const size_t lds = (size_t)4 * kWaveLds * 4;
-    if (fused)
-        hipLaunchKernelGGL((k_conv_first_fixed<QNN_STORE_I4, 2>), grid, block, lds, s, g, e, (const float*)x, w->d_wq, y,
-                           (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
-                           (uint32_t)img_x, wscale, vscale);
-    else
-        hipLaunchKernelGGL((k_conv_first_fixed<QNN_STORE_F32, 1>), grid, block, lds, s, g, e, (const float*)x, w->d_wq, y,
-                           (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
-                           (uint32_t)img_x, wscale, vscale);
+    const size_t lds = (size_t)4 * kWaveLds * 4 + 4 * 64 * 2 * 16;
+#define FIXED_LAUNCH(OUT_, POOL_, BIN_)                                                                                   \
+    hipLaunchKernelGGL((k_conv_first_fixed<OUT_, POOL_, BIN_>), grid, block, lds, s, g, e, (const float*)x, w->d_wq, y,    \
+                       (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc, \
+                       (uint32_t)img_x, wscale, vscale, 1.0f / vscale)
+    if (!fused) FIXED_LAUNCH(QNN_STORE_F32, 1, false);
+    else if (e.fn == QNN_FN_BINARY_TANH) FIXED_LAUNCH(QNN_STORE_I4, 2, true);
+    else FIXED_LAUNCH(QNN_STORE_I4, 2, false);
+#undef FIXED_LAUNCH
     return 0;
 }

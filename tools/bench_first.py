@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the float-input first layer of a BASELINE config on its own (HIP events behind queued launches).
-Env: IDX (baseline config index, default 2), N (batch, default 4096), QNN_FIRST_ABL (kernel ablations, timing only).
+Env: IDX (baseline config index, default 2), N (batch, default 4096), FIXED=1 (fixed-point variant), QNN_FIRST_ABL (kernel ablations, timing only).
 Prints one JSON line: kernel tag, us per launch, fraction of the 157.3 TFLOP/s f32 matrix peak."""
 import importlib
 import json
@@ -14,6 +14,8 @@ import torch  # noqa: E402
 pkg = importlib.import_module("quantizedneuralnetworks-keras-tensorflow_amd")
 nets, engine, abi = pkg.nets, pkg.engine, pkg._abi
 
+if os.environ.get("FIXED", "0") == "1":          # the opt-in fixed-point variant (csrc/qnn_first_fixed.hip)
+    abi.set_option("first_fixed", 1)
 idx = int(os.environ.get("IDX", "2"))
 N = int(os.environ.get("N", "4096"))
 cf = nets.baseline_config(idx)
