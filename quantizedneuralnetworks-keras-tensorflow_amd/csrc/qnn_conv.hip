@@ -535,10 +535,52 @@ __global__ __launch_bounds__(kBlock) void k_dense_packed(const uint32_t* __restr
     y[(size_t)img * units + u] = v;
 }
 
+// The same layer with the K loop of one (image, unit) cut over KP adjacent lanes (classifier heads: <= 16 units, so
+// one thread per (image, unit) leaves a 4096-image batch with 256 workgroups of long serial loops: 9.8 us for the
+// 4096 x 1024 -> 10 head of the CIFAR VGG against 2-3 us of memory time).  Integer partial sums: any order is exact.
+template <int XS, int UP, int KP>
+__global__ __launch_bounds__(kBlock) void k_dense_packed_split(const uint32_t* __restrict__ x,
+                                                               const uint32_t* __restrict__ wp, EpiArgs e,
+                                                               float* __restrict__ y, int N, int cin,
+                                                               int kwords, int units) {
+    constexpr int IPB = kBlock / (UP * KP);          // images per block
+    const int kp = threadIdx.x % KP;
+    const int u = (threadIdx.x / KP) % UP;
+    const int img = blockIdx.x * IPB + threadIdx.x / (UP * KP);
+    const bool live = img < N && u < units;
+    const uint32_t* xr = x + (size_t)(live ? img : 0) * kwords;
+    const uint32_t* wr = wp + (size_t)(live ? u : 0) * kwords;
+    int acc = 0;
+    for (int k = kp * 4; k + 4 <= kwords; k += 4 * KP) {
+        const uint4 a = *reinterpret_cast<const uint4*>(xr + k);
+        const uint4 w = *reinterpret_cast<const uint4*>(wr + k);
+        acc = qnn_dot<XS>(a.x, w.x, acc);
+        acc = qnn_dot<XS>(a.y, w.y, acc);
+        acc = qnn_dot<XS>(a.z, w.z, acc);
+        acc = qnn_dot<XS>(a.w, w.w, acc);
+    }
+#pragma unroll
+    for (int d = 1; d < KP; d <<= 1) acc += __shfl_xor(acc, d);     // every lane of the group takes part
+    if (!live || kp != 0) return;
+    if constexpr (XS == QNN_STORE_BIN) acc = cin - 2 * acc;   // pad bits are 0 in both operands
+    float v = __fmul_rn((float)acc, e.scale);
+    v = qnn_epi_value(v, u, e);
+    if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
+    else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
+    y[(size_t)img * units + u] = v;
+}
+
 template <int XS>
 int launch_dense(const void* x, const qnn_weights* w, const EpiArgs& e, void* y, int N, hipStream_t s) {
     const int units = w->cout;
     const uint32_t* xu = (const uint32_t*)x;
+    if (units <= 16 && (w->kwords % 16) == 0) {
+        constexpr int UP = 16, KP = 4;
+        const int ipb = kBlock / (UP * KP);
+        hipLaunchKernelGGL((k_dense_packed_split<XS, UP, KP>), dim3((N + ipb - 1) / ipb), dim3(kBlock), 0, s, xu,
+                           w->d_packed, e, (float*)y, N, w->cin, w->kwords, units);
+        return 0;
+    }
 #define DENSE_CASE(UP)                                                                           \
     if (units <= UP) {                                                                           \
         const int ipb = kBlock / UP;                                                             \
