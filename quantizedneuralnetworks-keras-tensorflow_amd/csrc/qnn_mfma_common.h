@@ -202,30 +202,36 @@ __device__ __forceinline__ float max4(float a, float b, float c, float d) {
                                          __builtin_elementwise_maximum(c, d));
 }
 
-// NV pre-scaled post-BN values (t * m) of one lane -> offset-coded fields of OBITS bits
+// NV pre-scaled post-BN values (t * m) of one lane -> offset-coded fields of OBITS bits.
+// rint + clamp in one float add and one integer median: t + (1.5 * 2^23 + OFF) rounds to an integer (ties to even, as
+// rint: the constant is even) whose float bits are kMagic + rint(t); v_med3_i32 clamps the bits to [kMagic - m,
+// kMagic + m - 1] (values beyond +-2^22, infinities included, order like their bits), so the low OBITS bits are
+// code + OFF.  The fields are assembled with shift-adds; the shifted copies of the constant cancel modulo 2^32.
 template <int OBITS, int NV>
 __device__ __forceinline__ uint32_t pack_scaled(const float* tm, float m, bool binary) {
-    constexpr int FPER = 16 / OBITS;                 // fields per exact 16-bit half
-    static_assert(NV % FPER == 0 && NV * OBITS <= 32, "fields must fill whole halves of one word");
-    constexpr int OFFSUM = (1 << (OBITS - 1)) * (OBITS == 4 ? 0x1111 : 0x0101);
-    float c[NV];
+    static_assert(NV * OBITS <= 32, "fields must fit one word");
+    constexpr int OFF = 1 << (OBITS - 1);
+    constexpr int kMagic = 0x4B400000 + OFF;                       // float bits of 1.5 * 2^23 + OFF
+    int cb[NV];
     if (binary) {
         asm volatile("; binary_tanh codes");         // keeps this a real (uniform) branch
 #pragma unroll
-        for (int j = 0; j < NV; ++j) c[j] = tm[j] > 0x1p-24f ? 1.0f : -1.0f;
+        for (int j = 0; j < NV; ++j) cb[j] = tm[j] > 0x1p-24f ? kMagic + 1 : kMagic - 1;
     } else {
+        const int lo = kMagic - (int)m, hi = kMagic + (int)m - 1;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) c[j] = __builtin_amdgcn_fmed3f(rintf(tm[j]), -m, m - 1.0f);
+        for (int j = 0; j < NV; ++j) {
+            const int bits = __float_as_int(__fadd_rn(tm[j], __int_as_float(kMagic)));
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cb[j]) : "v"(bits), "v"(lo), "v"(hi));
+        }
     }
-    uint32_t word = 0;
+    uint32_t word = (uint32_t)cb[0], bias = (uint32_t)(kMagic - OFF);
 #pragma unroll
-    for (int h = 0; h < NV / FPER; ++h) {
-        float S = (float)OFFSUM;
-#pragma unroll
-        for (int j = 0; j < FPER; ++j) S = __fmaf_rn(c[h * FPER + j], (float)(1 << (OBITS * j)), S);
-        word |= (uint32_t)S << (16 * h);
+    for (int j = 1; j < NV; ++j) {
+        word += (uint32_t)cb[j] << (OBITS * j);
+        bias += (uint32_t)(kMagic - OFF) << (OBITS * j);
     }
-    return word;
+    return word - bias;
 }
 
 }  // namespace
