@@ -251,6 +251,11 @@ template <int XS, int WM, int WN, int OUT, int POOL>
 __global__ void k_conv_mfma16(MfmaGeom mg, EpiArgs e, const uint8_t* __restrict__ x,
                               const uint8_t* __restrict__ wq8, void* __restrict__ y);
 
+// launch of the LDS-DMA variant (defined after the kernel: it takes the kernel's address)
+template <int XS, int WM, int WN, int OUT>
+void launch_dma16(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s,
+                  dim3 grid, dim3 block);
+
 template <int XS, int WM, int WN, int OUT>
 void launch_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
                  hipStream_t s) {
@@ -262,6 +267,14 @@ void launch_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     // the large tiles (16 / 8 waves per workgroup, four waves per SIMD) use the 16x16x64 shape
     if constexpr (OUT != QNN_STORE_BIN && WM == 4 && WN >= 2) {
         static const int shape = getenv("QNN_MFMA_SHAPE") ? atoi(getenv("QNN_MFMA_SHAPE")) : 16;
+        // int8 activations on the 256 x 256 tile: both operands go global -> LDS by LDS-DMA (see k_conv_mfma16)
+        if constexpr (XS == QNN_STORE_I8 && WM == 4 && WN == 4) {
+            static const int dma = getenv("QNN_MFMA_DMA") ? atoi(getenv("QNN_MFMA_DMA")) : 1;   // A/B switch, read once
+            if (shape == 16 && dma) {
+                launch_dma16<XS, WM, WN, OUT>(mg, e, x, w, y, s, grid, block);
+                return;
+            }
+        }
         if (shape == 16) {
             if (mg.g.pool == 2)
                 hipLaunchKernelGGL((k_conv_mfma16<XS, WM, WN, OUT, 2>), grid, block, lds, s, mg, e,
@@ -300,11 +313,16 @@ int launch_out(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_
 // of 16 bytes per step and wave), 16 MFMAs of 16 cycles instead of 8 of 32; the 64-byte rows
 // use a chunk permutation that is conflict-free for this fragment shape.  The 2x2 pool window
 // is still the four accumulator registers of one lane.  Outputs: float32, int4, int8.
-template <int XS, int WM, int WN, int OUT, int POOL>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2 : 3)) void k_conv_mfma16(MfmaGeom mg, EpiArgs e,
-                                                           const uint8_t* __restrict__ x,
-                                                           const uint8_t* __restrict__ wq8,
-                                                           void* __restrict__ y) {
+//
+// DMA variant (int8 activations, 16 waves): both operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds`
+// (no staging registers, no ds_write: the VGPR -> LDS store path costs 13 cycles per KiB and was busy 40 % of a
+// K-step), three LDS buffers, one raw s_barrier per K-step and a counted vmcnt, so two steps of loads stay in flight
+// across the barrier.  An LDS-DMA wave-instruction writes 64 x 16 bytes LINEARLY from its wave-uniform base: the
+// chunk swizzle moves to the source side (lane (row, slot) fetches chunk slot ^ swz(row) of its row); out-of-range
+// offsets (padding taps, steps past the end) write zeros.
+template <int XS, int WM, int WN, int OUT, int POOL, bool DMA>
+__device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiArgs& e, const uint8_t* __restrict__ x,
+                                                 const uint8_t* __restrict__ wq8, void* __restrict__ y) {
     constexpr int T = 64 * WM * WN;
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int RPP = T / 4;               // rows staged per pass
@@ -318,7 +336,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
     // chunk per 16 lanes; ds_read_b128 lane groups {0-3,12-15,20-27} ...) and for the staging writes
     auto swz = [](int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };      // {0,2,3,1}[(row>>2)&3]
     constexpr int A_BUF = BM * 64, B_BUF = BN * 64;
-    constexpr int B_BASE = 2 * A_BUF;
+    constexpr int NBUF = DMA ? 3 : 2;
+    constexpr int B_BASE = NBUF * A_BUF;
+    static_assert(!DMA || (XS == QNN_STORE_I8 && NA == 1 && NB == 1), "LDS-DMA staging: int8 rows, one chunk per thread");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
             const int py = (int)(qrow - (uint32_t)n * g.Hp);
             const int iy0 = (py * POOL + (sub >> 1)) * g.stride - g.pt;
             const int ix0 = (px * POOL + (sub & 1)) * g.stride - g.pl;
-            a_voff[p] = ((n * g.H + iy0) * g.W + ix0) * mg.x_pix_bytes + sch * XCH;
+            a_voff[p] = ((n * g.H + iy0) * g.W + ix0) * mg.x_pix_bytes + (DMA ? (sch ^ swz(R)) : sch) * XCH;
             for (int dy = 0; dy < g.kh; ++dy)
                 for (int dx = 0; dx < g.kw; ++dx)
                     if ((unsigned)(iy0 + dy) < (unsigned)g.H && (unsigned)(ix0 + dx) < (unsigned)g.W)
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
         const int R = srow + p * RPP;
-        b_voff[p] = (nbase + R) * w_row_bytes + sch * 16;
+        b_voff[p] = (nbase + R) * w_row_bytes + (DMA ? (sch ^ swz(R)) : sch) * 16;
         b_lds[p] = B_BASE + R * 64 + ((sch ^ swz(R)) << 4);
     }
 
@@ -455,12 +475,44 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
         __builtin_amdgcn_s_setprio(0);
     };
 
+    const int S = mg.steps;
+    if constexpr (DMA) {
+        // step k lives in buffer k % 3.  Per step: wait for this wave's own loads of step k (the loads of step k + 1
+        // stay in flight), barrier (every wave's part of step k is in LDS, every wave is done reading step k - 1),
+        // issue the loads of step k + 2 into the buffer step k - 1 used, then the MFMAs of step k.
+        using lds_ptr = __attribute__((address_space(3))) void*;
+        auto dma_issue = [&](int buf) {
+            const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
+            const int woff = s_tap < g.kh * g.kw ? s_tap * g.cin + s_kc * 64 : (int)0x40000000;   // past the end -> zeros
+            const bool ok = (a_mask[0] >> s_tap) & 1u;
+            const int voff = ok ? a_voff[0] + xoff : (int)0x80000000;                            // out of range -> zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(smem + buf * A_BUF + wave * 1024), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(smem + B_BASE + buf * B_BUF + wave * 1024), 16,
+                                                     b_voff[0], woff, 0, 0);
+            if (++s_kc == mg.kc) {
+                s_kc = 0; ++s_tap;
+                if (++s_dx == g.kw) { s_dx = 0; ++s_dy; }
+            }
+        };
+        dma_issue(0);                                  // step 0
+        dma_issue(1);                                  // step 1
+        int buf = 0, nxt = 2;                          // buffer of step ks, buffer of step ks + 2
+        for (int ks = 0; ks < S; ++ks) {
+            __builtin_amdgcn_s_waitcnt(0x0F72);        // vmcnt(2): step ks has landed, step ks + 1 may be in flight
+            __builtin_amdgcn_s_barrier();
+            dma_issue(nxt);                            // step ks + 2 (past the end: zeros, never read)
+            compute(buf * A_BUF, buf * B_BUF);
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): the fragment reads of this step are done
+            buf = buf == 2 ? 0 : buf + 1;
+            nxt = nxt == 2 ? 0 : nxt + 1;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): no load may land after the kernel's LDS is gone
+    } else {
     // ---- main loop: one barrier per K-step; the loads of step k+2 are issued before the
     // MFMAs of step k and only waited for (counted vmcnt) after the MFMAs of step k+1 ----
     // Loads are issued UNCONDITIONALLY (a step past the end has tap >= kh*kw, whose mask
     // bit is 0 -> out-of-range offset -> the buffer load returns zeros without touching
     // memory): conditional loads make the compiler fall back to vmcnt(0).
-    const int S = mg.steps;
     stage_load(raA, rbA);                          // step 0
     stage_load(raB, rbB);                          // step 1
     stage_write(raA, rbA, 0, 0);
@@ -477,6 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
         __syncthreads();
     }
     if (ks < S) compute(0, 0);                     // odd step count: last step sits in buffer 0
+    }
 
     // ---- epilogue: C/D layout of 16x16: lane holds column (lane & 15) and rows 4*(lane >> 4) + r
     // of each tile -> the four registers of a tile are one 2x2 pool window of one channel ----
@@ -590,6 +643,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
                     if (q < mg.total_q) ((uint32_t*)y)[q * e.ocw + ((cb + 16 * b) >> 2)] = Wd;
                 }
             }
+        }
+    }
+}
+
+template <int XS, int WM, int WN, int OUT, int POOL>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2 : 3)) void k_conv_mfma16(MfmaGeom mg, EpiArgs e,
+                                                           const uint8_t* __restrict__ x,
+                                                           const uint8_t* __restrict__ wq8,
+                                                           void* __restrict__ y) {
+    conv_mfma16_body<XS, WM, WN, OUT, POOL, false>(mg, e, x, wq8, y);
+}
+template <int XS, int WM, int WN, int OUT, int POOL>
+__global__ __launch_bounds__(64 * WM * WN, 4) void k_conv_mfma16_dma(MfmaGeom mg, EpiArgs e, const uint8_t* __restrict__ x,
+                                                                     const uint8_t* __restrict__ wq8, void* __restrict__ y) {
+    conv_mfma16_body<XS, WM, WN, OUT, POOL, true>(mg, e, x, wq8, y);
+}
+
+template <int XS, int WM, int WN, int OUT>
+void launch_dma16(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s,
+                  dim3 grid, dim3 block) {
+    if constexpr (XS == QNN_STORE_I8 && WM == 4 && WN == 4 && OUT != QNN_STORE_BIN) {
+        const size_t lds3 = 3 * (64 * WM + 64 * WN) * 64;
+        if (mg.g.pool == 2) {
+            (void)hipFuncSetAttribute((const void*)k_conv_mfma16_dma<XS, WM, WN, OUT, 2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            hipLaunchKernelGGL((k_conv_mfma16_dma<XS, WM, WN, OUT, 2>), grid, block, lds3, s, mg, e,
+                               (const uint8_t*)x, w, y);
+        } else {
+            (void)hipFuncSetAttribute((const void*)k_conv_mfma16_dma<XS, WM, WN, OUT, 1>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            hipLaunchKernelGGL((k_conv_mfma16_dma<XS, WM, WN, OUT, 1>), grid, block, lds3, s, mg, e,
+                               (const uint8_t*)x, w, y);
         }
     }
 }
