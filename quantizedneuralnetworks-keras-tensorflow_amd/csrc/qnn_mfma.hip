@@ -336,7 +336,7 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
     // chunk per 16 lanes; ds_read_b128 lane groups {0-3,12-15,20-27} ...) and for the staging writes
     auto swz = [](int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };      // {0,2,3,1}[(row>>2)&3]
     constexpr int A_BUF = BM * 64, B_BUF = BN * 64;
-    constexpr int NBUF = DMA ? 3 : 2;
+    constexpr int NBUF = DMA ? QNN_DMA_NBUF : 2;
     constexpr int B_BASE = NBUF * A_BUF;
     static_assert(!DMA || (XS == QNN_STORE_I8 && NA == 1 && NB == 1), "LDS-DMA staging: int8 rows, one chunk per thread");
 
@@ -477,9 +477,9 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
 
     const int S = mg.steps;
     if constexpr (DMA) {
-        // step k lives in buffer k % 3.  Per step: wait for this wave's own loads of step k (the loads of step k + 1
+        // step k lives in buffer k % NBUF (NBUF = 3: measured; see QNN_DMA_NBUF).  Per step: wait for this wave's own loads of step k (the loads of step k + 1
         // stay in flight), barrier (every wave's part of step k is in LDS, every wave is done reading step k - 1),
-        // issue the loads of step k + 2 into the buffer step k - 1 used, then the MFMAs of step k.
+        // issue the loads of step k + NBUF - 1 into the buffer step k - 1 used, then the MFMAs of step k.
         using lds_ptr = __attribute__((address_space(3))) void*;
         auto dma_issue = [&](int buf) {
             const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
@@ -494,17 +494,18 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
                 if (++s_dx == g.kw) { s_dx = 0; ++s_dy; }
             }
         };
-        dma_issue(0);                                  // step 0
-        dma_issue(1);                                  // step 1
-        int buf = 0, nxt = 2;                          // buffer of step ks, buffer of step ks + 2
+#pragma unroll
+        for (int i = 0; i < NBUF - 1; ++i) dma_issue(i);                   // steps 0 .. NBUF-2
+        int buf = 0, nxt = NBUF - 1;                   // buffer of step ks, buffer of step ks + NBUF - 1
         for (int ks = 0; ks < S; ++ks) {
-            __builtin_amdgcn_s_waitcnt(0x0F72);        // vmcnt(2): step ks has landed, step ks + 1 may be in flight
+            // vmcnt(2 * (NBUF - 2)): step ks has landed, the later steps may be in flight
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NBUF - 2)));
             __builtin_amdgcn_s_barrier();
             dma_issue(nxt);                            // step ks + 2 (past the end: zeros, never read)
             compute(buf * A_BUF, buf * B_BUF);
             __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): the fragment reads of this step are done
-            buf = buf == 2 ? 0 : buf + 1;
-            nxt = nxt == 2 ? 0 : nxt + 1;
+            buf = buf == NBUF - 1 ? 0 : buf + 1;
+            nxt = nxt == NBUF - 1 ? 0 : nxt + 1;
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): no load may land after the kernel's LDS is gone
     } else {
@@ -664,7 +665,7 @@ template <int XS, int WM, int WN, int OUT>
 void launch_dma16(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s,
                   dim3 grid, dim3 block) {
     if constexpr (XS == QNN_STORE_I8 && WM == 4 && WN == 4 && OUT != QNN_STORE_BIN) {
-        const size_t lds3 = 3 * (64 * WM + 64 * WN) * 64;
+        const size_t lds3 = (size_t)QNN_DMA_NBUF * (64 * WM + 64 * WN) * 64;
         if (mg.g.pool == 2) {
             (void)hipFuncSetAttribute((const void*)k_conv_mfma16_dma<XS, WM, WN, OUT, 2>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);

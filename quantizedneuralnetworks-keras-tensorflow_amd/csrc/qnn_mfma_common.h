@@ -13,6 +13,9 @@
 #ifndef QNN_SMALL32_WPC
 #define QNN_SMALL32_WPC 2
 #endif
+#ifndef QNN_DMA_NBUF
+#define QNN_DMA_NBUF 3          // LDS buffers of the LDS-DMA implicit GEMM (qnn_mfma.hip): loads run NBUF-1 K-steps ahead
+#endif
 #ifndef QNN_FIRST_WPS
 #define QNN_FIRST_WPS 3
 #endif
