@@ -708,7 +708,9 @@ class LayerModel:
             self.layers[i] = layer
         self.fuse_input_activation = fuse_input_activation
 
-    def forward(self, x):
+    def forward(self, x, upto=None):
+        """upto: index of a spec op whose output is returned instead of the network's (the intermediate model of
+        test_resnet.py:70-72, `Model(inputs=model.input, outputs=model.get_layer(name).output)`)."""
         x = _abi.require_cuda(x, "LayerModel.forward")
         g = self._graph
         env = {"input": x}
@@ -765,6 +767,8 @@ class LayerModel:
                     raise ValueError(kind)
             env[name] = y
             dom[name] = d
+            if upto is not None and i == upto:
+                return y
         return env[g._names[-1]]
 
     __call__ = forward

@@ -296,6 +296,22 @@ class Model:
         labels = y.argmax(-1) if y.ndim == 2 else y
         return float((p.argmax(-1) == labels).mean())
 
+    def conv_output(self, x, number, batch_size=256):
+        """Output of the `number`-th convolution (1-based, the order Keras names them conv2d_1, conv2d_2 ...), float32
+        NHWC, computed layer by layer behind the Keras-compatible float32 surface: the intermediate model of
+        test_resnet.py:70-81."""
+        import torch
+        from . import engine
+        convs = [i for i, op in enumerate(self.spec) if op["op"] == "conv"]
+        if not 1 <= number <= len(convs):
+            raise ValueError("conv number %d outside 1..%d" % (number, len(convs)))
+        if getattr(self, "_layer_model", None) is None:
+            self._layer_model = engine.LayerModel(self.spec)
+        x = torch.as_tensor(np.ascontiguousarray(x, dtype=F32))
+        outs = [self._layer_model.forward(x[i:i + batch_size].cuda(), upto=convs[number - 1]).cpu()
+                for i in range(0, x.shape[0], batch_size)]
+        return torch.cat(outs).numpy()
+
     def count_params(self):
         n = 0
         for op in self.spec:
@@ -322,6 +338,52 @@ def build_model(cf, seed=0, device="cuda"):
     """model_factory.py:18-72: config -> model (synthetic weights; use spec_from_keras_npz +
     Model(cf, spec) to run an imported checkpoint)."""
     return Model(cf, build_spec(cf, seed), device)
+
+
+def activation_range_probe(model, x, number, limit=63.0, batch_size=256):
+    """The check of test_resnet.py:70-89: does any value of the `number`-th convolution's output exceed `limit` in
+    magnitude (63 = what a 7-bit accumulator holds)?  Returns {"count", "max_abs", "first"} with `first` the
+    (element, value) pair the reference's loop would print first, or None."""
+    y = model.conv_output(x, number, batch_size)
+    a = np.abs(y)
+    over = a > limit
+    first = None
+    if over.any():
+        idx = np.argwhere(over)[0]                  # C order = the reference's elem / i / j / k loop nest
+        first = (int(idx[0]), float(a[tuple(idx)]))
+    return {"count": int(over.sum()), "max_abs": float(a.max()) if a.size else 0.0, "first": first}
+
+
+class Dataset:
+    """utils/load_data.py:38-42: X = uint8 / 255 as float32 (with a trailing channel axis for grey images), y as is."""
+
+    def __init__(self, dset, add_dim=False):
+        norm = np.asarray(dset[0]).astype("float32") / 255
+        self.X = norm.reshape(norm.shape + (1,)) if add_dim else norm
+        self.y = np.asarray(dset[1])
+
+
+def load_dataset(dataset, path, architecture="VGG", classes=10):
+    """utils/load_data.py:45-95 without the download: `path` is an .npz with x_train / y_train / x_test / y_test (the
+    layout of Keras' own `mnist.npz`; CIFAR-10 converted to the same four arrays).  Returns (train, valid, test) with
+    the reference's split (45 000 / 50 000 training images), its /255 normalisation, labels as one-hot rows
+    (load_data.py:79-82), mapped to +-1 for the VGG nets' hinge loss (84-88)."""
+    sizes = {"CIFAR-10": (45000, False), "MNIST": (50000, True), "FASHION": (50000, True)}
+    if dataset not in sizes:
+        raise ValueError(str(dataset) + " is not supported")
+    size, add_dim = sizes[dataset]
+    with np.load(path, allow_pickle=False) as z:
+        tr = (z["x_train"], z["y_train"])
+        te = (z["x_test"], z["y_test"])
+    size = min(size, len(tr[0]))
+    sets = [Dataset((tr[0][:size], tr[1][:size]), add_dim), Dataset((tr[0][size:], tr[1][size:]), add_dim),
+            Dataset(te, add_dim)]
+    for d in sets:
+        lab = d.y.reshape(-1).astype(np.int64)
+        onehot = np.zeros((lab.size, classes), dtype=F32)
+        onehot[np.arange(lab.size), lab] = 1.0
+        d.y = 2.0 * onehot - 1.0 if architecture == "VGG" else onehot
+    return tuple(sets)
 
 
 def synthetic_images(cf, n, seed=0):
