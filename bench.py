@@ -195,18 +195,23 @@ def layer_roof_ms(k):
     return max(k["bytes"] / (HBM_PEAK_GBS * 1e9), 2.0 * k["macs"] / peak) * 1e3
 
 
-def load_traffic(tag):
-    """HBM bytes per launch of kernel `tag` from the committed PMC passes (profiles/latest_traffic.json, written by
-    tools/summarize_profile.py; exact tag match).  rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE
-    counts 64 of every 128 fetched bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled."""
+def load_traffic(tag, workload):
+    """HBM bytes per launch of kernel `tag` from the committed PMC passes of `workload` (profiles/latest_traffic.json:
+    one `by_tag` table per profiled workload, written by tools/summarize_profile.py; exact tag match, a tag that
+    several profiled kernels share is not listed).  rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE
+    counts 64 of every 128 fetched bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled -- except for the
+    strip kernels, whose loads are 8 and 2 bytes per lane ("other access widths are uncalibrated: calibrate on a known
+    byte count"): a 64 x 224^2 x 16 layer with packed shortcut must read between 51.4 MB (both tensors once) and 60.4 MB
+    (with every halo row and column) and reports FETCH_SIZE 52.3 MB, so the factor there is 1."""
     path = os.path.join(ROOT, "profiles", "latest_traffic.json")
     try:
-        ent = json.load(open(path)).get("by_tag", {}).get(tag)
+        ent = json.load(open(path)).get("by_workload", {}).get(workload, {}).get(tag)
     except (OSError, ValueError):
         return None, None
     if not ent or "fetch_kb" not in ent or "write_kb" not in ent:
         return None, None
-    return (2.0 * ent["fetch_kb"] + ent["write_kb"]) * 1024.0, ent.get("rocprof_kernel")
+    factor = 1.0 if tag.startswith("strip_") else 2.0
+    return (factor * ent["fetch_kb"] + ent["write_kb"]) * 1024.0, ent.get("rocprof_kernel")
 
 
 def main_rank(args):
@@ -434,7 +439,8 @@ def main_rank(args):
         value = global_batch * args.steps / dt
         d = per_kernel[dom]
         hbm_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        traffic, rocprof_name = load_traffic(d["kernel"])
+        tkey = d["kernel"] + (":%s" % d["shape"][-1] if d.get("shape") and str(d["shape"][-1]).startswith("res_") else "")
+        traffic, rocprof_name = load_traffic(tkey, args.workload + ("+first_fixed" if args.first_layer == "fixed" else ""))
         common = {"kernel": d["kernel"], "rocprof_kernel": rocprof_name, "layer_index": dom,
                   "launches_per_step": d["launches"], "avg_launch_ms": d["ms"],
                   "back_to_back_launch_ms": d.get("b2b_ms"),

@@ -20,4 +20,6 @@ python3 $ROOT/tools/summarize_profile.py $OUT $OUT/traffic.json $OUT/bench_trace
 cat $OUT/summary.txt
 # keep the merged-back payload small
 find $OUT -name "*.db" -delete; find $OUT -name "*agent_info*" -delete
+# the per-dispatch CSVs of a 63-kernel forward run to tens of MB: the summary above is what is kept
+find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*_counter_collection.csv" -delete
 du -sh $OUT

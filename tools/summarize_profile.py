@@ -51,10 +51,15 @@ TAG_PATTERNS = [
     (r"^mfma_i(\d)_areg64x64$", r"^k_conv_mfma_areg<\1,"),
     (r"^mfma_i(\d)_wres256x64$", r"^k_conv_mfma_wres<\1,"),
     (r"^mfma_i4_small_c(\d+)$", r"^k_conv_mfma_small<\1,"),
+    (r"^mfma_i8x3_first_fixed$", r"^k_conv_first_fixed<"),
+    (r"^strip_i4_c(\d+)_s2(:res_\w+)?$", r"^k_conv_strip_s2<\1,"),
+    (r"^strip_i4_c(\d+):res_none$", r"^k_conv_strip<\1, \d, 0,"),
+    (r"^strip_i4_c(\d+):res_packed$", r"^k_conv_strip<\1, \d, 1,"),
+    (r"^strip_i4_c(\d+):res_f32$", r"^k_conv_strip<\1, \d, 2,"),
     (r"^strip_i4_c(\d+)$", r"^k_conv_strip<\1,"),
     (r"^mfma_i(\d)_(\d+)x(\d+)$", None),          # tile sizes -> waves, handled below
-    (r"^dense_i(\d)$", r"^k_dense_packed<\1,"),
-    (r"^dense_bin$", r"^k_dense_packed<1,"),
+    (r"^dense_i(\d)$", r"^k_dense_packed(_split)?<\1,"),
+    (r"^dense_bin$", r"^k_dense_packed(_split)?<1,"),
     (r"^dense_f32$", r"^k_dense_f32in"),
     (r"^xnor_f32_cw(\d+)$", r"^k_conv_xnor_f32<\1>"),
     (r"^xnor_pk_cw(\d+)", r"^k_conv_xnor_pk<\1,"),
@@ -64,16 +69,20 @@ TAG_PATTERNS = [
 
 
 def rocprof_names_for(tag, names):
+    """`tag` is what qnn_last_kernel() reports, optionally with the residual kind bench.py's launch groups carry
+    (`strip_i4_c16:res_packed`); a suffix no pattern knows is ignored."""
     import re
+    if ":" in tag and not any(re.match(t, tag) for t, _ in TAG_PATTERNS):
+        tag = tag.split(":")[0]
     for tpat, kpat in TAG_PATTERNS:
         m = re.match(tpat, tag)
         if not m:
             continue
         if kpat is None:
             bits, bm, bn = m.group(1), int(m.group(2)) // 64, int(m.group(3)) // 64
-            kre = re.compile(r"^k_conv_mfma(16)?<%s, %d, %d," % (bits, bm, bn))
+            kre = re.compile(r"^k_conv_mfma(16)?(_dma)?<%s, %d, %d," % (bits, bm, bn))
         else:
-            kre = re.compile(m.expand(kpat))
+            kre = re.compile(kpat.replace(r"\1", m.group(1)) if m.groups() else kpat)
         return [n for n in names if kre.match(n)]
     return []
 
@@ -104,7 +113,10 @@ def traffic_json(root, out_path, bench_json=None):
             line = line.strip()
             if line.startswith("{"):
                 try:
-                    tags = [k["kernel"] for k in json.loads(line).get("kernels", [])]
+                    for k in json.loads(line).get("kernels", []):
+                        tags.append(k["kernel"])
+                        if k.get("shape") and str(k["shape"][-1]).startswith("res_"):
+                            tags.append("%s:%s" % (k["kernel"], k["shape"][-1]))
                 except ValueError:
                     pass
     by_tag = {}
@@ -115,7 +127,35 @@ def traffic_json(root, out_path, bench_json=None):
     json.dump({"by_tag": by_tag, "by_kernel": res}, open(out_path, "w"), indent=1, sort_keys=True)
 
 
+def retag(traffic_path, bench_log):
+    """Rebuild `by_tag` of an existing traffic.json from its `by_kernel` (after TAG_PATTERNS changed)."""
+    import json
+    d = json.load(open(traffic_path))
+    res = d["by_kernel"]
+    tags = []
+    for line in open(bench_log):
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                for k in json.loads(line).get("kernels", []):
+                    tags.append(k["kernel"])
+                    if k.get("shape") and str(k["shape"][-1]).startswith("res_"):
+                        tags.append("%s:%s" % (k["kernel"], k["shape"][-1]))
+            except ValueError:
+                pass
+    by_tag = {}
+    for tag in dict.fromkeys(tags):
+        names = rocprof_names_for(tag, list(res))
+        if len(names) == 1:
+            by_tag[tag] = dict(res[names[0]], rocprof_kernel=names[0])
+    d["by_tag"] = by_tag
+    json.dump(d, open(traffic_path, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--retag":
+        retag(sys.argv[2], sys.argv[3])
+        sys.exit(0)
     main(sys.argv[1])
     if len(sys.argv) > 2:
         traffic_json(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
