@@ -494,6 +494,52 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
                 if (++s_dx == g.kw) { s_dx = 0; ++s_dy; }
             }
         };
+#if QNN_DMA_PREFETCH
+        // Fragment prefetch: the operand registers of step k + 1 are filled WHILE the MFMAs of step k run (the B
+        // fragments into a second register set, each A fragment into its own registers as soon as its row of MFMAs has
+        // been issued), so a step starts on the matrix pipe right after its barrier instead of after 8 LDS reads that
+        // all 16 waves issue at once.  The wait / barrier at the top of step k therefore covers the loads of step
+        // k + 1, and the loads issued at step k go three steps ahead, into the buffer step k just vacated.
+        static_assert(NBUF == 3, "the prefetching schedule rotates three buffers");
+        if (true) {
+            dma_issue(0); dma_issue(1); dma_issue(2);
+            v4i fa[4], fb[2][4];
+            auto read_a = [&](int t, int b_) { return *reinterpret_cast<const v4i*>(smem + fa_addr + b_ * A_BUF + t * 1024); };
+            auto read_b = [&](int t, int b_) { return *reinterpret_cast<const v4i*>(smem + fb_addr + b_ * B_BUF + t * 1024); };
+            __builtin_amdgcn_s_waitcnt(0x0F74);        // vmcnt(4): step 0 has landed
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { fa[t] = read_a(t, 0); fb[0][t] = read_b(t, 0); }
+            int buf = 0;                               // buffer of step ks
+            auto step = [&](auto curc) {
+                constexpr int C = decltype(curc)::value;
+                const int nb = buf == 2 ? 0 : buf + 1; // buffer of step ks + 1
+                __builtin_amdgcn_s_waitcnt(0x0072);    // vmcnt(2): step ks + 1 has landed;  lgkmcnt(0): this step's fragments are in
+                __builtin_amdgcn_s_barrier();          // ... for every wave, and every wave has read buffer `buf` for the last time
+                dma_issue(buf);                        // step ks + 3 (past the end: zeros, never used)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fb[1 - C][t] = read_b(t, nb);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[C][b], acc[a][b], 0, 0, 0);
+                    fa[a] = read_a(a, nb);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                buf = nb;
+            };
+            int ks = 0;
+            for (; ks + 2 <= S; ks += 2) {
+                step(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 1>{});
+            }
+            if (ks < S) step(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0), lgkmcnt(0): nothing may land after the kernel's LDS is gone
+        } else
+#endif
+        {
 #pragma unroll
         for (int i = 0; i < NBUF - 1; ++i) dma_issue(i);                   // steps 0 .. NBUF-2
         int buf = 0, nxt = NBUF - 1;                   // buffer of step ks, buffer of step ks + NBUF - 1
@@ -508,6 +554,7 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
             nxt = nxt == NBUF - 1 ? 0 : nxt + 1;
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): no load may land after the kernel's LDS is gone
+        }
     } else {
     // ---- main loop: one barrier per K-step; the loads of step k+2 are issued before the
     // MFMAs of step k and only waited for (counted vmcnt) after the MFMAs of step k+1 ----

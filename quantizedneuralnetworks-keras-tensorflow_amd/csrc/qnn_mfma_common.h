@@ -16,6 +16,9 @@
 #ifndef QNN_DMA_NBUF
 #define QNN_DMA_NBUF 3          // LDS buffers of the LDS-DMA implicit GEMM (qnn_mfma.hip): loads run NBUF-1 K-steps ahead
 #endif
+#ifndef QNN_DMA_PREFETCH
+#define QNN_DMA_PREFETCH 1      // LDS-DMA implicit GEMM: fill the next K-step's operand registers under this step's MFMAs
+#endif
 #ifndef QNN_FIRST_WPS
 #define QNN_FIRST_WPS 3
 #endif
