@@ -11,7 +11,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k(int iters, int* out) {
+__global__ __launch_bounds__(256, 2) void k(int iters, int* out) {
     v4i a = {(int)threadIdx.x * 0x01010101, 0x11223344, 0x55667788, 0x7f017f01}, b = {0x04050607, 0x01020304, 0x7f7f7f7f, (int)blockIdx.x};
     v4i acc4[8]; v16i acc16[4]; v4f accf4[8]; v16f accf16[4];
     for (int i = 0; i < 8; ++i) { acc4[i] = v4i{0, 0, 0, 0}; accf4[i] = v4f{0, 0, 0, 0}; }
@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void k(int iters, int* out) {
         }
     }
     int s = 0;
-    for (int i = 0; i < 8; ++i) s ^= acc4[i][0] ^ acc4[i][3] ^ __float_as_int(accf4[i][1]);
-    for (int i = 0; i < 4; ++i) s ^= acc16[i][0] ^ acc16[i][15] ^ __float_as_int(accf16[i][7]);
+    // every accumulator element is used: a partial use lets the compiler split the tuples and shuffle AGPRs in the loop
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) s ^= acc4[i][j] ^ __float_as_int(accf4[i][j]);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s ^= acc16[i][j] ^ __float_as_int(accf16[i][j]);
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
