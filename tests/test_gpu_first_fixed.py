@@ -112,6 +112,32 @@ def test_fused_codes_match_the_specification_and_rarely_differ_from_the_oracle(c
     assert rate <= 2e-3
 
 
+def test_inputs_outside_the_unit_interval_saturate(fixed_first_layer):
+    """The kernel's domain is images / 255; values outside [0, 1] are clamped (the specification's np.clip), so a
+    caller who feeds something else gets a defined result, not wrapped digits."""
+    rng, x, op = _case("q4_32", (2, 16, 32, 3), "quantized", 4)
+    x = x.copy()
+    x[0, :4] = 1.5
+    x[0, 4:8] = -0.25
+    x[1, 0, 0] = [0.0, 1.0, 1.0 - 2.0 ** -24]
+    got, kern = _run_group(x, None, op, None, None, 1, _abi.STORE_F32)
+    assert kern == "mfma_i8x3_first_fixed"
+    np.testing.assert_array_equal(got, _fixed_conv(x, op))
+    np.testing.assert_array_equal(got[0, 1:3], _fixed_conv(np.clip(x, 0, 1), op)[0, 1:3])
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 24, 3), (2, 15, 16, 3), (1, 16, 16, 1)], ids=["w24", "h15", "cin1"])
+def test_shapes_outside_the_domain_keep_the_exact_kernel(shape, fixed_first_layer):
+    rng = np.random.default_rng(3)
+    x = (rng.integers(0, 256, shape).astype(F32) / F32(255)).astype(F32)
+    op = {"op": "conv", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (3, 3, shape[3], 64)).astype(F32),
+          "strides": (1, 1), "padding": "same"}
+    bn = _rand_bn(rng, 64, 9 * shape[3] * 0.3)
+    got, kern = _run_group(x, None, op, bn, Q(4), 2, _abi.STORE_I4)
+    assert "fixed" not in kern
+    np.testing.assert_array_equal(got, _oracle_group(x, op, bn, Q(4), 2, float_conv="device"))
+
+
 def test_headline_network_with_the_fixed_point_first_layer(fixed_first_layer):
     """BASELINE configs[2] (VGG-64 4/4, the headline workload) at batch 256: logits with the fixed-point first layer against the oracle's."""
     cf = nets.baseline_config(2)
