@@ -268,7 +268,7 @@ void launch_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     if constexpr (OUT != QNN_STORE_BIN && WM == 4 && WN >= 2) {
         static const int shape = getenv("QNN_MFMA_SHAPE") ? atoi(getenv("QNN_MFMA_SHAPE")) : 16;
         // int8 activations on the 256 x 256 tile: both operands go global -> LDS by LDS-DMA (see k_conv_mfma16)
-        if constexpr (XS == QNN_STORE_I8 && WM == 4 && WN == 4) {
+        if constexpr (XS == QNN_STORE_I8 && WM == 4 && (WN == 4 || WN == 2)) {
             static const int dma = getenv("QNN_MFMA_DMA") ? atoi(getenv("QNN_MFMA_DMA")) : 1;   // A/B switch, read once
             if (shape == 16 && dma) {
                 launch_dma16<XS, WM, WN, OUT>(mg, e, x, w, y, s, grid, block);
@@ -338,7 +338,8 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
     constexpr int A_BUF = BM * 64, B_BUF = BN * 64;
     constexpr int NBUF = DMA ? QNN_DMA_NBUF : 2;
     constexpr int B_BASE = NBUF * A_BUF;
-    static_assert(!DMA || (XS == QNN_STORE_I8 && NA == 1 && NB == 1), "LDS-DMA staging: int8 rows, one chunk per thread");
+    static_assert(!DMA || XS == QNN_STORE_I8, "LDS-DMA staging: int8 rows (int4 rows are widened in registers)");
+    constexpr int NLD = NA + NB;             // LDS-DMA loads per thread and K-step
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -484,11 +485,18 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
         auto dma_issue = [&](int buf) {
             const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
             const int woff = s_tap < g.kh * g.kw ? s_tap * g.cin + s_kc * 64 : (int)0x40000000;   // past the end -> zeros
-            const bool ok = (a_mask[0] >> s_tap) & 1u;
-            const int voff = ok ? a_voff[0] + xoff : (int)0x80000000;                            // out of range -> zeros
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr)(smem + buf * A_BUF + wave * 1024), 16, voff, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr)(smem + B_BASE + buf * B_BUF + wave * 1024), 16,
-                                                     b_voff[0], woff, 0, 0);
+            // pass p of a tile = rows [p * RPP, (p + 1) * RPP): wave w writes the 1 KiB at p * RPP * 64 + w * 1024
+#pragma unroll
+            for (int p = 0; p < NA; ++p) {
+                const bool ok = (a_mask[p] >> s_tap) & 1u;
+                const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;                        // out of range -> zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    xrsrc, (lds_ptr)(smem + buf * A_BUF + p * (RPP * 64) + wave * 1024), 16, voff, 0, 0, 0);
+            }
+#pragma unroll
+            for (int p = 0; p < NB; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    wrsrc, (lds_ptr)(smem + B_BASE + buf * B_BUF + p * (RPP * 64) + wave * 1024), 16, b_voff[p], woff, 0, 0);
             if (++s_kc == mg.kc) {
                 s_kc = 0; ++s_tap;
                 if (++s_dx == g.kw) { s_dx = 0; ++s_dy; }
@@ -506,7 +514,7 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
             v4i fa[4], fb[2][4];
             auto read_a = [&](int t, int b_) { return *reinterpret_cast<const v4i*>(smem + fa_addr + b_ * A_BUF + t * 1024); };
             auto read_b = [&](int t, int b_) { return *reinterpret_cast<const v4i*>(smem + fb_addr + b_ * B_BUF + t * 1024); };
-            __builtin_amdgcn_s_waitcnt(0x0F74);        // vmcnt(4): step 0 has landed
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NLD));   // vmcnt: step 0 has landed (two steps may be in flight)
             __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int t = 0; t < 4; ++t) { fa[t] = read_a(t, 0); fb[0][t] = read_b(t, 0); }
@@ -514,7 +522,7 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
             auto step = [&](auto curc) {
                 constexpr int C = decltype(curc)::value;
                 const int nb = buf == 2 ? 0 : buf + 1; // buffer of step ks + 1
-                __builtin_amdgcn_s_waitcnt(0x0072);    // vmcnt(2): step ks + 1 has landed;  lgkmcnt(0): this step's fragments are in
+                __builtin_amdgcn_s_waitcnt(0x0070 | NLD);   // vmcnt(NLD): step ks + 1 has landed;  lgkmcnt(0): this step's fragments are in
                 __builtin_amdgcn_s_barrier();          // ... for every wave, and every wave has read buffer `buf` for the last time
                 dma_issue(buf);                        // step ks + 3 (past the end: zeros, never used)
 #pragma unroll
@@ -545,7 +553,7 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
         int buf = 0, nxt = NBUF - 1;                   // buffer of step ks, buffer of step ks + NBUF - 1
         for (int ks = 0; ks < S; ++ks) {
             // vmcnt(2 * (NBUF - 2)): step ks has landed, the later steps may be in flight
-            __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NBUF - 2)));
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (NLD * (NBUF - 2)));
             __builtin_amdgcn_s_barrier();
             dma_issue(nxt);                            // step ks + 2 (past the end: zeros, never read)
             compute(buf * A_BUF, buf * B_BUF);
@@ -711,7 +719,7 @@ __global__ __launch_bounds__(64 * WM * WN, 4) void k_conv_mfma16_dma(MfmaGeom mg
 template <int XS, int WM, int WN, int OUT>
 void launch_dma16(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s,
                   dim3 grid, dim3 block) {
-    if constexpr (XS == QNN_STORE_I8 && WM == 4 && WN == 4 && OUT != QNN_STORE_BIN) {
+    if constexpr (XS == QNN_STORE_I8 && WM == 4 && (WN == 4 || WN == 2) && OUT != QNN_STORE_BIN) {
         const size_t lds3 = (size_t)QNN_DMA_NBUF * (64 * WM + 64 * WN) * 64;
         if (mg.g.pool == 2) {
             (void)hipFuncSetAttribute((const void*)k_conv_mfma16_dma<XS, WM, WN, OUT, 2>,
