@@ -484,11 +484,12 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
         using lds_ptr = __attribute__((address_space(3))) void*;
         auto dma_issue = [&](int buf) {
             const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
-            const int woff = s_tap < g.kh * g.kw ? s_tap * g.cin + s_kc * 64 : (int)0x40000000;   // past the end -> zeros
+            const int woff = (s_tap < g.kh * g.kw && !(mg.ablate & 2)) ? s_tap * g.cin + s_kc * 64
+                                                                        : (int)0x40000000;   // past the end -> zeros
             // pass p of a tile = rows [p * RPP, (p + 1) * RPP): wave w writes the 1 KiB at p * RPP * 64 + w * 1024
 #pragma unroll
             for (int p = 0; p < NA; ++p) {
-                const bool ok = (a_mask[p] >> s_tap) & 1u;
+                const bool ok = ((a_mask[p] >> s_tap) & 1u) && !(mg.ablate & 1);                 // (ablate: timing experiments)
                 const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;                        // out of range -> zeros
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     xrsrc, (lds_ptr)(smem + buf * A_BUF + p * (RPP * 64) + wave * 1024), 16, voff, 0, 0, 0);
