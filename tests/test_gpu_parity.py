@@ -218,6 +218,12 @@ LAYER_CASES = [
     ("i4_128_64", (2, 12, 12, 128), 64, 3, 1, "quantized", 4, Q(4), "ps_i4_cw16_k3"),
     ("i8_128_64", (3, 9, 7, 128), 64, 3, 1, "quantized", 8, Q(8), ""),
     ("i4_128_64_s2", (5, 13, 13, 128), 64, 3, 2, "quantized", 4, Q(4), "ps_i4_cw16_k3"),
+    # 256-filter multiples with int8 activations: the LDS-DMA staged 256x256 GEMM (one K-step, three 64-channel chunks per
+    # tap, stride 2 with ragged tiles, two filter slices)
+    ("i8_64_256_1x1", (2, 9, 7, 64), 256, 1, 1, "quantized", 8, Q(8), ""),
+    ("i8_192_256", (1, 10, 6, 192), 256, 3, 1, "quantized", 8, Q(8), ""),
+    ("i8_256_512_s2", (2, 12, 12, 256), 512, 3, 2, "quantized", 8, Q(8), ""),
+    ("i8_w4_a8_64_256", (3, 16, 16, 64), 256, 3, 1, "quantized", 4, Q(8), ""),
 ]
 
 
