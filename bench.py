@@ -113,20 +113,53 @@ def launch_ranks(args, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = procs[0].stdout.read()
+    return supervise(procs, deadline_s=float(os.environ.get("QNN_BENCH_DEADLINE_S", "3600")))
+
+
+def supervise(procs, deadline_s=3600.0, poll_s=0.05):
+    """Wait for the ranks WITHOUT ever blocking on one of them: rank 0's stdout is drained on a thread while every
+    child is polled.  The first rank that exits non-zero (or the deadline) kills the others -- they would sit in the
+    rendezvous / a collective until c10d's timeout -- and its status becomes the launcher's, within a poll interval.
+    Rank 0's last stdout line is relayed only when every rank exited 0."""
+    import threading
+    chunks = []
+
+    def drain(pipe):
+        for chunk in iter(lambda: pipe.read(65536), b""):
+            chunks.append(chunk)
+
+    reader = None
+    if procs and procs[0].stdout is not None:
+        reader = threading.Thread(target=drain, args=(procs[0].stdout,), daemon=True)
+        reader.start()
     rc = 0
-    deadline = time.time() + 3600
-    for p in procs:
-        try:
-            code = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            code = -9
-        if code != 0 and rc == 0:
-            rc = code if code > 0 else 1
-            for q in procs:                   # one rank failed: the others would wait in a collective for ever
-                if q.poll() is None:
-                    q.kill()
-    lines = [l for l in out0.decode(errors="replace").splitlines() if l.strip()]
+    deadline = time.time() + deadline_s
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+        if rc == 0 and live and time.time() > deadline:
+            sys.stderr.write("bench.py: ranks still running after %.0f s; killing them\n" % deadline_s)
+            rc = 124
+        if rc != 0:
+            for q in live:                    # one rank failed: the others would wait in a collective for ever
+                q.kill()
+            for q in live:
+                try:
+                    q.wait(timeout=10)
+                except subprocess.TimeoutExpired:   # pragma: no cover
+                    pass
+            live = []
+        elif live:
+            time.sleep(poll_s)
+    if reader is not None:
+        reader.join(timeout=10)
+    lines = [l for l in b"".join(chunks).decode(errors="replace").splitlines() if l.strip()]
     if rc == 0 and lines:
         sys.stdout.write(lines[-1] + "\n")
         sys.stdout.flush()

@@ -31,6 +31,20 @@ void qnn_set_kernel_name(const char* name);
         }                                                                      \
     } while (0)
 
+// ---- measurement scaffolding ------------------------------------------------------
+// A/B switches read from the environment and the operand-load ablations of the GEMM exist ONLY in builds made with
+// -DQNN_EXPERIMENTS (tools/build_variant.py <name> <file.hip> -DQNN_EXPERIMENTS ...).  The default library reads no
+// environment variable on its dispatch paths and carries no ablation code: every switch is its compiled-in default.
+#ifdef QNN_EXPERIMENTS
+#define QNN_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define QNN_ENV_STR(name) getenv(name)
+#define QNN_ABLATE(word, bit) (((word) & (bit)) != 0)
+#else
+#define QNN_ENV_INT(name, dflt) (dflt)
+#define QNN_ENV_STR(name) ((const char*)nullptr)
+#define QNN_ABLATE(word, bit) false
+#endif
+
 // ---- opaque weights handle --------------------------------------------------
 struct qnn_weights {
     int wkind, wbits;

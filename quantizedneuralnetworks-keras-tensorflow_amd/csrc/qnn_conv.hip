@@ -939,7 +939,7 @@ int try_launch_xnor_f32(const ConvGeom& g, const EpiArgs& e, int in_fn, const fl
     // strip height: whole image if it fits in ~32 KB of LDS, else as many rows as fit
     int TR = g.H;
     while ((size_t)(TR + 2) * g.W * cw * 4 > 32768 && TR > 1) TR = (TR + 1) / 2;
-    static const int tr_env = getenv("QNN_XNOR_TR") ? atoi(getenv("QNN_XNOR_TR")) : 0;
+    static const int tr_env = QNN_ENV_INT("QNN_XNOR_TR", 0);
     if (tr_env > 0 && tr_env < TR) TR = tr_env;
     else if (tr_env == 0 && TR > 8 && (TR % 8) == 0) TR = 8;    // measured: more, smaller items overlap load and compute better
     const int strips = (g.H + TR - 1) / TR;

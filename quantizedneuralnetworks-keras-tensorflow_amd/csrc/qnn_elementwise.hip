@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void k_tern_sum(const float* __restrict__ x
         double t = 0.0;
         for (int i = 0; i < kBlock / 64; ++i) t += part[i];
         atomicAdd(sum, t);
+        if (blockIdx.x == 0) atomicAdd(sum + 1, (double)n);      // the element count (the workspace was zeroed)
     }
 }
 // pass 2: W > cutoff -> 1, W <= -cutoff -> -1, else 0; then W + (Wt - W)
@@ -307,8 +308,9 @@ extern "C" int qnn_quantized_tanh_f32(const float* x, float* y, size_t n, int nb
 extern "C" int qnn_ternary_abs_sum_f32(const float* x, size_t n, void* workspace16, void* stream) {
     QNN_REQUIRE(x && workspace16, QNN_EINVAL, "qnn_ternary_abs_sum_f32: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const double init[2] = {0.0, (double)n};
-    QNN_HIP(hipMemcpyAsync(workspace16, init, 16, hipMemcpyHostToDevice, s));
+    // a memset node, not a copy from host memory: this call is captured into hipGraphs (a pageable host source would be
+    // read at replay time, long after this frame is gone); the kernel adds the count itself
+    QNN_HIP(hipMemsetAsync(workspace16, 0, 16, s));
     if (n == 0) return QNN_OK;
     const int g = grid_for(n) < 1024 ? grid_for(n) : 1024;
     hipLaunchKernelGGL(k_tern_sum, dim3(g), dim3(kBlock), 0, s, x, n, (double*)workspace16);

@@ -389,14 +389,14 @@ __global__ __launch_bounds__(256, QNN_FIRST_WPS) void k_conv_first_lds(ConvGeom 
 #elif QNN_FIRST_PRIO == 2
             __builtin_amdgcn_s_setprio(1);
 #endif
-            if (nc + 2 >= NT && !(abl & 2)) {
+            if (nc + 2 >= NT && !QNN_ABLATE(abl, 2)) {
                 __builtin_amdgcn_sched_barrier(0);
                 stage_write(0);
                 fetch_operands();
                 if (periodic) stage_load_next(); else stage_load(min(t + 2 * nwaves, tiles - 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (abl & 1) {                       // timing experiment: no epilogue arithmetic, one raw store
+            if (QNN_ABLATE(abl, 1)) {                       // timing experiment: no epilogue arithmetic, one raw store
                 if (acc[0][0] + acc[1][0] == 123.456f) ytile[lane_off + nc * 4] = 1u;
                 continue;
             }
@@ -472,7 +472,7 @@ int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float
     const double xb = (double)g.N * g.H * g.W * CIN * 4.0;
     if (xb >= 2.0e9) return 1;                  // 31-bit buffer offsets
     const uint32_t x_bytes = (uint32_t)xb;
-    static const int no_lds = getenv("QNN_FIRST_GATHER") ? atoi(getenv("QNN_FIRST_GATHER")) : 0;
+    static const int no_lds = QNN_ENV_INT("QNN_FIRST_GATHER", 0);
     const bool lds_ok = !no_lds && NT == 2 && g.stride == 1 && g.pt == 1 && g.pl == 1 &&
                         ((g.pool == 2 && (g.Wp % 8) == 0 && (g.H % 2) == 0 && (g.W % 2) == 0) ||
                          (g.pool == 1 && (g.W % 32) == 0));
@@ -488,7 +488,7 @@ int launch_first(const ConvGeom& g, const EpiArgs& e, const void* x, const float
             const FastDiv fd_tpr = qnn_fastdiv((uint32_t)tpr);
             const size_t lds_bytes = (size_t)4 * (g.pool == 2 ? 4 * first_lds_row_stride(18 * CIN) : 3 * 34 * CIN) * 4   // one tile per wave
                                      + (size_t)NT * 32 * 9 * CIN * 4;                                                  // + the block's filters
-            static const int abl = getenv("QNN_FIRST_ABL") ? atoi(getenv("QNN_FIRST_ABL")) : 0;   // timing experiments only
+            static const int abl = QNN_ENV_INT("QNN_FIRST_ABL", 0);   // timing ablations: experiment builds only
 #define FIRST_LDS_CASE(OUT)                                                                      \
             if (e.out_store == OUT) {                                                            \
                 if (g.pool == 2)                                                                 \

@@ -265,7 +265,7 @@ int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* 
     const double img_x = (double)g.H * g.W * 3 * 4.0;
     if (img_x >= 1.0e9 || (double)g.N * g.Hp * g.Wp * 8.0 >= 2.0e9 * 4) return 1;
     const int hp2 = g.H / 2;
-    static const int bpc = getenv("QNN_FIXED_BPC") ? atoi(getenv("QNN_FIXED_BPC")) : 4;   // A/B switch, read once
+    static const int bpc = QNN_ENV_INT("QNN_FIXED_BPC", 4);   // A/B switch (experiment builds only)
     const int blocks_cap = 256 * (bpc >= 1 && bpc <= 5 ? bpc : 4);
     const long nwaves = (long)blocks_cap * 4;
     int best_rc = hp2, best_nch = 1;

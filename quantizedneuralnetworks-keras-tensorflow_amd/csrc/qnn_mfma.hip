@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
     {
         const unsigned nb_ = gridDim.x, b_ = blockIdx.x;
         const unsigned q_ = nb_ / 8, r_ = nb_ % 8, xcd = b_ % 8, idx = b_ / 8;
-        tile = (mg.ablate & 4) ? (long)b_
+        tile = QNN_ABLATE(mg.ablate, 4) ? (long)b_
                                : (long)((xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx);
     }
     const int nbase = blockIdx.y * BN;
@@ -127,11 +127,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
     uint4 rbA[NB], rbB[NB];
     auto stage_load = [&](araw_t (&ra)[NA], uint4 (&rb)[NB]) {
         const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
-        const int woff = (s_tap < g.kh * g.kw && !(mg.ablate & 2)) ? s_tap * g.cin + s_kc * 64
+        const int woff = (s_tap < g.kh * g.kw && !QNN_ABLATE(mg.ablate, 2)) ? s_tap * g.cin + s_kc * 64
                                                                     : (int)0x40000000;   // past the end -> zeros
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
-            const bool ok = ((a_mask[p] >> s_tap) & 1u) && !(mg.ablate & 1);
+            const bool ok = ((a_mask[p] >> s_tap) & 1u) && !QNN_ABLATE(mg.ablate, 1);
             const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;   // out of range -> zeros
             if constexpr (XS == QNN_STORE_I8)
                 ra[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
@@ -177,13 +177,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16 ? 4 : WM * WN >= 8 ? 2
                 fa[t] = *reinterpret_cast<const v4i*>(smem + fa_addr[t][kk] + bufoff_a);
                 fb[t] = *reinterpret_cast<const v4i*>(smem + fb_addr[t][kk] + bufoff_b);
             }
-            if (!(mg.ablate & 8)) __builtin_amdgcn_s_setprio(1);
+            if (!QNN_ABLATE(mg.ablate, 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
-            if (!(mg.ablate & 8)) __builtin_amdgcn_s_setprio(0);
+            if (!QNN_ABLATE(mg.ablate, 8)) __builtin_amdgcn_s_setprio(0);
         }
     };
 
@@ -266,10 +266,10 @@ void launch_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     const size_t lds = 2 * (BM + BN) * 64;
     // the large tiles (16 / 8 waves per workgroup, four waves per SIMD) use the 16x16x64 shape
     if constexpr (OUT != QNN_STORE_BIN && WM == 4 && WN >= 2) {
-        static const int shape = getenv("QNN_MFMA_SHAPE") ? atoi(getenv("QNN_MFMA_SHAPE")) : 16;
+        static const int shape = QNN_ENV_INT("QNN_MFMA_SHAPE", 16);
         // int8 activations on the 256 x 256 tile: both operands go global -> LDS by LDS-DMA (see k_conv_mfma16)
         if constexpr (XS == QNN_STORE_I8 && WM == 4 && (WN == 4 || WN == 2)) {
-            static const int dma = getenv("QNN_MFMA_DMA") ? atoi(getenv("QNN_MFMA_DMA")) : 1;   // A/B switch, read once
+            static const int dma = QNN_ENV_INT("QNN_MFMA_DMA", 1);   // A/B switch (experiment builds only)
             if (shape == 16 && dma) {
                 launch_dma16<XS, WM, WN, OUT>(mg, e, x, w, y, s, grid, block);
                 return;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
     {
         const unsigned nb_ = gridDim.x, b_ = blockIdx.x;
         const unsigned q_ = nb_ / 8, r_ = nb_ % 8, xcd = b_ % 8, idx = b_ / 8;
-        tile = (mg.ablate & 4) ? (long)b_
+        tile = QNN_ABLATE(mg.ablate, 4) ? (long)b_
                                : (long)((xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx);
     }
     const int nbase = blockIdx.y * BN;
@@ -420,11 +420,11 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
     uint4 rbA[NB], rbB[NB];
     auto stage_load = [&](araw_t (&ra)[NA], uint4 (&rb)[NB]) {
         const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
-        const int woff = (s_tap < g.kh * g.kw && !(mg.ablate & 2)) ? s_tap * g.cin + s_kc * 64
+        const int woff = (s_tap < g.kh * g.kw && !QNN_ABLATE(mg.ablate, 2)) ? s_tap * g.cin + s_kc * 64
                                                                     : (int)0x40000000;   // past the end -> zeros
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
-            const bool ok = ((a_mask[p] >> s_tap) & 1u) && !(mg.ablate & 1);
+            const bool ok = ((a_mask[p] >> s_tap) & 1u) && !QNN_ABLATE(mg.ablate, 1);
             const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;   // out of range -> zeros
             if constexpr (XS == QNN_STORE_I8)
                 ra[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0));
@@ -484,12 +484,12 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
         using lds_ptr = __attribute__((address_space(3))) void*;
         auto dma_issue = [&](int buf) {
             const int xoff = (s_dy * g.W + s_dx) * mg.x_pix_bytes + s_kc * (4 * XCH);
-            const int woff = (s_tap < g.kh * g.kw && !(mg.ablate & 2)) ? s_tap * g.cin + s_kc * 64
+            const int woff = (s_tap < g.kh * g.kw && !QNN_ABLATE(mg.ablate, 2)) ? s_tap * g.cin + s_kc * 64
                                                                         : (int)0x40000000;   // past the end -> zeros
             // pass p of a tile = rows [p * RPP, (p + 1) * RPP): wave w writes the 1 KiB at p * RPP * 64 + w * 1024
 #pragma unroll
             for (int p = 0; p < NA; ++p) {
-                const bool ok = ((a_mask[p] >> s_tap) & 1u) && !(mg.ablate & 1);                 // (ablate: timing experiments)
+                const bool ok = ((a_mask[p] >> s_tap) & 1u) && !QNN_ABLATE(mg.ablate, 1);                 // (ablate: timing experiments)
                 const int voff = ok ? a_voff[p] + xoff : (int)0x80000000;                        // out of range -> zeros
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     xrsrc, (lds_ptr)(smem + buf * A_BUF + p * (RPP * 64) + wave * 1024), 16, voff, 0, 0, 0);
@@ -797,7 +797,7 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     }
     if (!w->d_mfma) return 1;
     if (x_store != QNN_STORE_I8 && x_store != QNN_STORE_I4) return 1;
-    static const bool small_off = getenv("QNN_MFMA_SMALL_OFF") != nullptr;   // A/B switch, read once
+    static const bool small_off = QNN_ENV_STR("QNN_MFMA_SMALL_OFF") != nullptr;   // A/B switch (experiment builds only)
     // 3x3 stride-1 int4 layers with 16 / 32 / 64 input channels: row-walking strip kernel (qnn_mfma_strip.hip).
     // The residual's post-scale (models/resnet.py:128: 0.5) must be a power of two so that it folds exactly into the
     // activation's code scale.
@@ -852,6 +852,9 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
         }
     }
     if (g.cin % 64 != 0 || g.cout % 64 != 0) return 1;
+    // the tiled kernels keep the in-image taps of a pixel in a 32-bit mask and shift it by up to kh*kw + 2 (the
+    // past-the-end LDS-DMA steps): larger windows (not reachable today, qnn_prepack_weights stops at 3x3) fall back
+    if (g.kh * g.kw + 3 > 32) return 1;
     const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
     if (g.cout % pw != 0) return 1;
     MfmaGeom mg;
@@ -865,12 +868,12 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     if (xb >= 2.0e9 || wb >= 2.0e9) return 1;          // 31-bit buffer offsets
     mg.x_bytes = (uint32_t)xb;
     mg.w_bytes = (uint32_t)wb;
-    static const int ablate = getenv("QNN_MFMA_ABLATE") ? atoi(getenv("QNN_MFMA_ABLATE")) : 0;
+    static const int ablate = QNN_ENV_INT("QNN_MFMA_ABLATE", 0);
     mg.ablate = ablate;
     EpiArgs e2 = e;
     if (x_store == QNN_STORE_I4) e2.scale = e.scale * (1.0f / 256.0f);   // both operands carry *16
     // tile shape: waves along M x waves along N (64x64 per wave)
-    static const char* tile_env = getenv("QNN_MFMA_TILE");
+    static const char* tile_env = QNN_ENV_STR("QNN_MFMA_TILE");
     int wm_ = 4, wn_ = 1;
     if ((g.cout % 256) == 0) { wm_ = 4; wn_ = 4; }          // measured: 256x256 > 128x256 > 256x128 > 128x128
     else if ((g.cout % 128) == 0) { wm_ = 4; wn_ = 2; }
@@ -879,12 +882,12 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
         if (em >= 1 && en >= 1 && (g.cout % (64 * en)) == 0) { wm_ = em; wn_ = en; }
     }
     // short-K layers with one 64-filter slice: weight-resident persistent kernel
-    static const int wres_env = getenv("QNN_MFMA_WRES") ? atoi(getenv("QNN_MFMA_WRES")) : -1;
+    static const int wres_env = QNN_ENV_INT("QNN_MFMA_WRES", -1);
     const long rows_ = mg.total_q * (g.pool == 2 ? 4 : 1);
     const bool wres_fit = mg.steps <= 12 && rows_ < 2000000000L;
     const bool wres = wres_env == 0 ? false : wres_env == 1 ? wres_fit : (wres_fit && g.cout == 64 && !tile_env);
     // 3x3, Cin <= 128: operands straight into registers (QNN_MFMA_AREG=0 disables, =1 also for Cout > 64)
-    static const int areg_env = getenv("QNN_MFMA_AREG") ? atoi(getenv("QNN_MFMA_AREG")) : -1;
+    static const int areg_env = QNN_ENV_INT("QNN_MFMA_AREG", -1);
     const bool areg_fit = g.kh == 3 && g.kw == 3 && mg.kc <= 2 && rows_ < 2000000000L;
     const bool areg = areg_env == 0 ? false : areg_env == 1 ? areg_fit : (areg_fit && g.cout == 64 && !tile_env && wres_env < 0);
     if (e.res && !(areg && g.pool == 1)) return 1;          // the other MFMA kernels have no residual epilogue

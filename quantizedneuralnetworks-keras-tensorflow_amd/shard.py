@@ -44,18 +44,24 @@ def gather_logits(local, total=None, group=None):
     return out if total is None else out[:total]
 
 
-_ACTIVE = []          # stack of process groups inside `with sharded(group):`
+_ACTIVE = []          # stack of (process group, valid rows) inside `with sharded(group):`
 
 
 class sharded:
     """Context in which batch tensors are SHARDS of a global batch: ops that reduce over the whole batch
-    tensor (ternary_tanh, ternary_ops.py:23) all-reduce their partial sums over `group`."""
+    tensor (ternary_tanh, ternary_ops.py:23) all-reduce their partial sums over `group`.
 
-    def __init__(self, group=None):
+    valid_rows: number of REAL images at the front of this rank's shard when it was zero-padded to the
+    common size (shard_batch).  The padded images still produce non-zero pre-activations (bias, BN shift),
+    so batch-wide statistics must not see them: reductions take the first `valid_rows` batch rows only."""
+
+    def __init__(self, group=None, valid_rows=None):
         self.group = group
+        self.valid_rows = valid_rows
 
     def __enter__(self):
-        _ACTIVE.append(self.group if self.group is not None else (dist.group.WORLD if dist.is_initialized() else None))
+        g = self.group if self.group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+        _ACTIVE.append((g, self.valid_rows))
         return self
 
     def __exit__(self, *exc):
@@ -63,11 +69,16 @@ class sharded:
         return False
 
 
+def active_valid_rows():
+    """Valid batch rows of the innermost `sharded` context (None: every row is a real image)."""
+    return _ACTIVE[-1][1] if _ACTIVE else None
+
+
 def allreduce_sum_count(ws, group=None):
     """Sum the {sum|clip(x)|, count} pair of ternary_tanh over the shards (in place).  No-op outside a sharded
     context / for a single process."""
     if group is None and _ACTIVE:
-        group = _ACTIVE[-1]
+        group = _ACTIVE[-1][0]
     elif group is None:
         return ws
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -90,6 +101,6 @@ def sharded_forward(model, x_global, rank, world, group=None):
     full-tnn network thresholds its ternary activations at the global batch mean."""
     total = x_global.shape[0]
     lo, hi, per = shard_bounds(total, rank, world)
-    with sharded(group):
+    with sharded(group, valid_rows=hi - lo):      # a ragged last shard is zero-padded: keep the padding out of the statistics
         local = model(shard_batch(x_global, rank, world))
     return gather_logits(local, total, group)

@@ -190,3 +190,16 @@ def test_one_bit_layers_choose_the_matrix_pipe_by_shape_and_impl():
         assert _abi.conv_impl() == _abi.IMPL_VALU
     finally:
         _abi._conv_impl = saved
+
+
+def test_default_library_carries_no_measurement_scaffolding():
+    """The A/B environment switches and the GEMM's operand ablations are compiled in only with -DQNN_EXPERIMENTS
+    (tools/build_variant.py): the shipped library must not even contain their names."""
+    import importlib
+    b = importlib.import_module("quantizedneuralnetworks-keras-tensorflow_amd._build")
+    blob = open(b.LIB, "rb").read()
+    for name in (b"QNN_MFMA_ABLATE", b"QNN_FIRST_ABL", b"QNN_MFMA_TILE", b"QNN_MFMA_SHAPE", b"QNN_MFMA_DMA",
+                 b"QNN_MFMA_AREG", b"QNN_MFMA_WRES", b"QNN_MFMA_SMALL_OFF", b"QNN_FIRST_GATHER", b"QNN_FIXED_BPC",
+                 b"QNN_XNOR_TR"):
+        assert name not in blob, name
+    assert "-DQNN_EXPERIMENTS" not in " ".join(b.CFLAGS)

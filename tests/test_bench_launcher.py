@@ -100,3 +100,39 @@ def test_real_process_on_a_box_without_enough_gpus_fails_loudly():
         pytest.skip("this box really has two GPUs")
     assert p.returncode != 0 and p.stdout.strip() == ""
     assert "--gpus 2 but this box has" in p.stderr
+
+
+def _child(code):
+    return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE)
+
+
+def test_supervise_real_children_failed_rank_ends_the_job_quickly(capsys):
+    """REAL child processes: rank 1 exits 3 at once while rank 0 would sit in the rendezvous (a 60 s sleep holding its
+    stdout pipe open).  The launcher must come back with 3 within seconds, kill rank 0 and print no JSON."""
+    import time
+    r0 = _child("import time, sys; sys.stdout.write('partial'); sys.stdout.flush(); time.sleep(60)")
+    r1 = subprocess.Popen([sys.executable, "-c", "import sys; sys.exit(3)"])
+    t0 = time.time()
+    rc = bench.supervise([r0, r1], deadline_s=120.0)
+    dt = time.time() - t0
+    assert rc == 3 and dt < 5.0, (rc, dt)
+    assert r0.poll() is not None                                  # rank 0 was killed, not left behind
+    assert capsys.readouterr().out == ""
+
+
+def test_supervise_real_children_deadline(capsys):
+    import time
+    r0 = _child("import time; time.sleep(60)")
+    r1 = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(60)"])
+    t0 = time.time()
+    rc = bench.supervise([r0, r1], deadline_s=1.0)
+    assert rc == 124 and time.time() - t0 < 8.0
+    assert r0.poll() is not None and r1.poll() is not None
+    assert capsys.readouterr().out == ""
+
+
+def test_supervise_real_children_success_relays_last_line(capsys):
+    r0 = _child("print('RCCL noise'); print('{\"n_gpus\": 2}')")
+    r1 = subprocess.Popen([sys.executable, "-c", "pass"])
+    assert bench.supervise([r0, r1], deadline_s=60.0) == 0
+    assert capsys.readouterr().out.strip().splitlines() == ['{"n_gpus": 2}']

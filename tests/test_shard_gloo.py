@@ -25,6 +25,50 @@ def _fake_forward(x):
     return torch.tanh(x.reshape(x.shape[0], -1) @ w)
 
 
+def _tnn_forward(x):
+    """CPU stand-in for a ternary network layer with the structure of the GPU op (layers/ternary_ops.ternary_tanh):
+    non-zero pre-activations for zero images (bias), partial {sum|clip|, count} over this shard's VALID rows only,
+    all-reduce through the active `shard.sharded` context, threshold applied to every row."""
+    pre = x.reshape(x.shape[0], -1) * 3.0 - 1.2 + 0.4            # "conv + bias": padded (zero) images give -0.8
+    valid = shard.active_valid_rows()
+    rows = pre if valid is None else pre[:valid]
+    ws = torch.stack([rows.clamp(-1, 1).abs().double().sum(), torch.tensor(float(rows.numel()), dtype=torch.float64)])
+    shard.allreduce_sum_count(ws)
+    cut = 0.7 * (ws[0] / ws[1]).float()
+    w = pre.clamp(-1, 1)
+    t = torch.where(w > cut, torch.ones_like(w), torch.where(w <= -cut, -torch.ones_like(w), torch.zeros_like(w)))
+    return t[:, :10].contiguous()
+
+
+def _worker_tnn(rank, world, port, total, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = torch.rand((total, 4, 4, 3), generator=torch.Generator().manual_seed(1))
+        y = shard.sharded_forward(_tnn_forward, x, rank, world)
+        if rank == 0:
+            torch.save({"y": y}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_shards_keep_padding_out_of_the_ternary_statistics(tmp_path):
+    """total = 13 on two ranks: rank 1 holds 6 images + 1 zero image.  The zero image's pre-activations (-0.8) must not
+    enter the all-reduced mean: the gathered result equals the single-process one (shard.py:93)."""
+    for total in (13, 16):
+        x = torch.rand((total, 4, 4, 3), generator=torch.Generator().manual_seed(1))
+        want = _tnn_forward(x)                                   # no sharded context: one process, every row valid
+        out = str(tmp_path / ("tnn_%d.pt" % total))
+        mp.spawn(_worker_tnn, args=(2, _free_port(), total, out), nprocs=2, join=True)
+        got = torch.load(out, weights_only=True)["y"]
+        assert torch.equal(got, want), total
+    # the statistic really is sensitive to the padding: with every row of the padded shard counted it moves
+    x = torch.rand((13, 4, 4, 3), generator=torch.Generator().manual_seed(1))
+    padded = torch.cat([x, torch.zeros((1, 4, 4, 3))])
+    assert not torch.equal(_tnn_forward(padded)[:13], _tnn_forward(x))
+
+
 def _worker(rank, world, port, total, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
