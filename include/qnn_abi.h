@@ -29,6 +29,12 @@
  *                  2- and 3-bit activations are stored sign-extended in 4 bits.
  *   QNN_STORE_I8   signed 8-bit codes, 4 per uint32.
  *   Words per pixel = ceil(C / (32 / bits)).
+ *
+ * Typed image input (first layer only):
+ *   QNN_STORE_U8   the dataset's own bytes: NHWC, C unsigned bytes per pixel, no padding; value = code / 255,
+ *                  which is how the reference forms its float32 images (utils/load_data.py:40:
+ *                  `dset[0].astype('float32') / 255`).  The domain [0, 1] is guaranteed by the type, the /255
+ *                  happens inside the layer, and the contraction is an exact integer sum (see qnn_conv2d_forward).
  */
 #ifndef QNN_ABI_H
 #define QNN_ABI_H
@@ -40,7 +46,7 @@
 extern "C" {
 #endif
 
-#define QNN_ABI_VERSION 2
+#define QNN_ABI_VERSION 3
 
 /* status codes */
 #define QNN_OK            0
@@ -54,6 +60,7 @@ extern "C" {
 #define QNN_STORE_BIN 1
 #define QNN_STORE_I4  4
 #define QNN_STORE_I8  8
+#define QNN_STORE_U8  16  /* input only: unsigned image bytes, value = code / 255 */
 
 /* weight quantizers (what the layer applies to its latent fp32 kernel) */
 #define QNN_W_FLOAT    0   /* stock Conv2D / Dense: kernel used as is          */
@@ -116,7 +123,9 @@ int         qnn_set_conv_impl(int impl);
  *                        run in fixed point (inputs rounded to 2^-23, exact int32 sums on the int8 matrix pipe, one
  *                        rounding): within 27 * 2^-24 + half an ulp of the REAL-number convolution, hence inside the
  *                        1e-5 contract, but not the float32 FMA chain of the default kernel -- activation codes whose
- *                        pre-activation sits that close to a rounding threshold can differ from the oracle's. */
+ *                        pre-activation sits that close to a rounding threshold can differ from the oracle's.
+ *                        Inputs outside [0, 1] (NaN included) are NOT silently saturated: the kernel raises the
+ *                        layer's domain flag, see qnn_weights_check(). */
 int         qnn_set_option(const char* key, int value);
 
 /* ---- elementwise activation clips on float32 tensors --------------------- */
@@ -172,6 +181,17 @@ int qnn_prepack_weights(int wkind, int wbits, float H, const float* kernel,
 int qnn_free_weights(qnn_weights_t* w);
 /* read back the quantized kernel as float32 HWIO into a DEVICE buffer (tests) */
 int qnn_weights_dequant(const qnn_weights_t* w, float* kernel_hwio, void* stream);
+/*
+ * Domain flag of a layer.  A kernel with a restricted input domain (today: the "first_fixed" variant, inputs in
+ * [0, 1]) raises a flag inside the handle when it meets a value outside it; the affected outputs are unspecified.
+ * The flag is reported -- and cleared -- as QNN_EINVAL by
+ *   - qnn_weights_check(w, stream): synchronises `stream` first, so every launch enqueued on it has been seen
+ *     (the sync point a caller places before it trusts the results of a batch);
+ *   - the next qnn_conv2d_forward on the handle, if the flag has already become visible to the host by then
+ *     (no synchronisation; a convenience, not a guarantee).
+ * Layers whose kernels accept every input never raise it: the call is then just the stream synchronisation.
+ */
+int qnn_weights_check(const qnn_weights_t* w, void* stream);
 
 /* ---- the contractions ------------------------------------------------------ */
 /*
@@ -179,8 +199,18 @@ int qnn_weights_dequant(const qnn_weights_t* w, float* kernel_hwio, void* stream
  * QuantizedConv2D.call (layers/quantized_layers.py:164-194), with the
  * lr-multiplier identity trick treated as the identity ("exact" mode).
  *   x        : DEVICE, NHWC; x_store = QNN_STORE_F32 (any float32 values: the
- *              first layer, or the generic fallback) or a packed kind
- *   x_bits   : abits of the packed codes (value = code/2^(x_bits-1); BIN: 1)
+ *              first layer, or the generic fallback), a packed kind, or QNN_STORE_U8
+ *   x_bits   : abits of the packed codes (value = code/2^(x_bits-1); BIN: 1; U8: ignored)
+ *
+ * QNN_STORE_U8 (image bytes, value = code/255; low-bit weights of <= 8 bits, no residual): with the integer weight
+ * codes k = w * 2^wshift the convolution is the EXACT integer S = sum code * k, and everything the launch fuses
+ * behind it is one affine map of S, evaluated as ONE float32 fused multiply-add per value:
+ *     t = fma((float)S, A[c], B[c]),   A = inv[c] * m / (255 * 2^wshift),  B = (bias[c] * inv[c] + shift[c]) * m
+ * (A, B formed in float64 from the float32 constants and rounded once; inv = 1, shift = 0 without BN; m = 2^(act_bits-1)
+ * for quantized_tanh, else 1), then  quantized_tanh: code = clip(rint(t), -m, m-1);  binary_tanh: +1 iff t > 2^-24;
+ * none: t.  t is within 1.5 ulp of the real-number value of the reference's expression on the same image, i.e. closer
+ * to it than any float32 evaluation order of the reference's own op sequence; it is NOT bit-identical to the
+ * float32-input path on x = code/255 (whose products are rounded one by one).
  *   y        : DEVICE, NHWC (N, Ho/pool, Wo/pool, cout) float32 or packed
  * Output geometry: Ho = ceil(H/stride) for 'same'.
  */

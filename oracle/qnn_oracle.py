@@ -1,15 +1,22 @@
 """CPU oracle for the low-bit forward path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
 
-PARITY UNPINNED vs TensorFlow: the reference (/root/reference) ships no golden
-vectors, no known-answer tests and no test-suite for this path, and neither
-``keras`` nor ``tensorflow`` is importable here, so the reference cannot be run.
 This file restates, in float32 numpy, exactly the op sequence the reference's
 Python emits (file:line cited per function) on top of the *documented* TF
 semantics it delegates to (tf.round = round-half-to-even, SAME padding,
-NHWC/HWIO cross-correlation, tf.nn.batch_normalization op order).  It is pinned
-only by (i) the hand-derived known-answer tables in tests/test_oracle_ops.py and
-(ii) the real trained weights in tests/golden/resnet3_*.npz (extracted from the
-reference's results/RESNET3/*.hdf5 by tests/golden/make_fixtures_from_hdf5.py).
+NHWC/HWIO cross-correlation, tf.nn.batch_normalization op order).
+
+PINNED by vectors produced by running the reference's OWN source in place
+(tests/golden/make_fixtures_from_reference.py imports layers/*_ops.py,
+layers/*_layers.py, models/vgg.py, models/resnet.py, models/model_factory.py from
+/root/reference under an eager numpy stand-in for the few keras.backend /
+tensorflow primitives they call, and writes tests/golden/ref_{ops,layers,models}.npz;
+tests/test_reference_fixtures.py checks every function below against them), by the
+hand-derived known-answer tables in tests/test_oracle_ops.py and by the real trained
+weights in tests/golden/resnet3_*.npz (extracted from the reference's
+results/RESNET3/*.hdf5 by tests/golden/make_fixtures_from_hdf5.py).
+STILL UNPINNED: TensorFlow itself was never run (not installable offline), so the
+summation order inside its Conv2D / MatMul kernels and its rsqrt are restated from
+documentation, not measured.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  The product path never calls it and has no CPU fallback.
@@ -474,6 +481,100 @@ def signs_of(xb):
 
 
 # --------------------------------------------------------------------------
+# Typed image input (include/qnn_abi.h, QNN_STORE_U8): the dataset's bytes, value = code / 255
+# (utils/load_data.py:40).  Restated specification of what the C ABI documents, NOT reference code: the
+# reference only ever sees the float32 quotient.  S = sum code * k is an exact integer (k = weight * 2^wshift),
+# and everything fused behind it is ONE float32 FMA t = fma(S, A, B).
+# --------------------------------------------------------------------------
+def weight_codes(op):
+    """(integer codes HWIO, wshift) of a low-bit conv op of a net spec."""
+    kind = op["kind"]
+    if kind == "binary":
+        return signs_of(binarize(op["kernel"], op.get("H", 1.0))), 0
+    if kind == "ternary":
+        return np.rint(ternarize(op["kernel"], op.get("H", 1.0))).astype(np.int64), 0
+    if kind == "quantized":
+        nb = int(op["nb"])
+        return codes_of(quantize(op["kernel"], nb), nb), nb - 1
+    raise ValueError("QNN_STORE_U8 input needs a low-bit layer, got %r" % kind)
+
+
+def u8_affine(bias, bn, m, D, cout):
+    """A = inv*m/D, B = (bias*inv + shift)*m: float64 arithmetic on the float32 constants, one rounding each."""
+    if bn is not None:
+        inv, shift = bn_constants(bn["gamma"], bn["beta"], bn["mean"], bn["var"], bn["eps"])
+    else:
+        inv, shift = np.ones(cout, F32), np.zeros(cout, F32)
+    b = _f32(bias) if bias is not None else np.zeros(cout, F32)
+    i64, s64, b64 = inv.astype(np.float64), shift.astype(np.float64), b.astype(np.float64)
+    A = (i64 * float(m) / float(D)).astype(np.float32)
+    B = ((b64 * i64 + s64) * float(m)).astype(np.float32)
+    return A, B
+
+
+def u8_conv_group(x_u8, op, bn=None, act=None):
+    """conv (uint8 image in) [-> bn] [-> binary_tanh | quantized_tanh]: float32 NHWC values."""
+    x_u8 = np.asarray(x_u8)
+    assert x_u8.dtype == np.uint8
+    k, ws = weight_codes(op)
+    S = int_conv2d(x_u8.astype(np.int64), k, tuple(op.get("strides", (1, 1))), op.get("padding", "same"))
+    assert np.abs(S).max(initial=0) < 2 ** 24
+    m = float(2 ** (int(act["nb"]) - 1)) if act is not None and act["fn"] == "quantized_tanh" else 1.0
+    A, B = u8_affine(op.get("bias"), bn, m, 255.0 * 2.0 ** ws, k.shape[3])
+    t = fma32(S.astype(np.float32), A[None, None, None, :], B[None, None, None, :])
+    if act is None:
+        return t
+    if act["fn"] == "binary_tanh":
+        return np.where(t > F32(2.0 ** -24), F32(1), F32(-1)).astype(np.float32)
+    if act["fn"] == "quantized_tanh":
+        return (np.clip(np.rint(t), -m, m - 1) / F32(m)).astype(np.float32)
+    raise ValueError(act["fn"])
+
+
+def _u8_group(spec):
+    """Ops the engines fuse behind a uint8-input first conv: the conv, a BN that is its only consumer and a low-bit
+    activation that is the BN's (or conv's) only consumer.  Returns (bn index or None, act index or None, next index)."""
+    def consumers(i):
+        name = spec[i].get("dst", "t%d" % i)
+        cons = []
+        for j, o in enumerate(spec):
+            if j == i:
+                continue
+            if o["op"] == "add":
+                if name in (o["a"], o["b"]):
+                    cons.append(j)
+            elif "src" in o:
+                if o["src"] == name:
+                    cons.append(j)
+            elif j == i + 1:
+                cons.append(j)
+        return cons
+    bn_i = act_i = None
+    nxt = 1
+    if len(spec) > nxt and spec[nxt]["op"] == "bn" and consumers(0) == [nxt]:
+        bn_i = nxt
+        nxt += 1
+    last = bn_i if bn_i is not None else 0
+    if len(spec) > nxt and spec[nxt]["op"] == "act" and consumers(last) == [nxt] and \
+            (spec[nxt]["fn"] == "binary_tanh" or (spec[nxt]["fn"] == "quantized_tanh" and spec[nxt]["nb"] <= 8)):
+        act_i = nxt
+        nxt += 1
+    return bn_i, act_i, nxt
+
+
+def run_spec_u8(spec, x_u8, return_all=False):
+    """run_spec for uint8 images through the typed entry: the first conv group follows u8_conv_group, every later op
+    is the exact-mode interpreter (all later layers are grid x grid, hence bit-exact integers)."""
+    assert spec[0]["op"] == "conv"
+    bn_i, act_i, nxt = _u8_group(spec)
+    y = u8_conv_group(x_u8, spec[0], spec[bn_i] if bn_i is not None else None,
+                      spec[act_i] if act_i is not None else None)
+    last = nxt - 1
+    env0 = {"input": None, spec[last].get("dst", "t%d" % last): y}
+    return _run_spec(spec, y, "exact", "legacy", return_all, start=nxt, env0=env0)
+
+
+# --------------------------------------------------------------------------
 # Whole-network interpreter over a neutral "net spec" (list of op dicts).
 # Topologies follow models/vgg.py:5-44 and models/resnet.py:26-144; the spec is
 # produced by the product's nets.py builder (plain numpy data, no code shared).
@@ -490,10 +591,12 @@ def run_spec(spec, x, mode="exact", promotion="legacy", return_all=False, float_
         FLOAT_CONV["order"] = "ideal"
 
 
-def _run_spec(spec, x, mode, promotion, return_all):
-    env = {"input": _f32(x)}
-    cur = env["input"]
+def _run_spec(spec, x, mode, promotion, return_all, start=0, env0=None):
+    env = {"input": _f32(x)} if env0 is None else dict(env0)
+    cur = _f32(x)
     for i, op in enumerate(spec):
+        if i < start:
+            continue
         kind = op["op"]
         src = env[op["src"]] if "src" in op else cur
         if kind == "conv":

@@ -13,7 +13,7 @@ import torch
 from . import _build
 
 QNN_OK = 0
-STORE_F32, STORE_BIN, STORE_I4, STORE_I8 = 0, 1, 4, 8
+STORE_F32, STORE_BIN, STORE_I4, STORE_I8, STORE_U8 = 0, 1, 4, 8, 16
 W_FLOAT, W_BINARY, W_QUANT, W_TERNARY = 0, 1, 2, 3
 FN_NONE, FN_BINARY_TANH, FN_QUANTIZED_TANH, FN_TERNARY_TANH, FN_GRID = 0, 1, 2, 3, 4
 
@@ -22,7 +22,7 @@ EXPORTS = [
     "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
     "qnn_ternary_abs_sum_f32", "qnn_ternary_apply_f32",
     "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32", "qnn_avgpool_packed_f32",
-    "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant",
+    "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant", "qnn_weights_check",
     "qnn_conv2d_forward", "qnn_dense_forward", "qnn_conv2d_forward_f32in", "qnn_conv2d_workspace_bytes",
 ]
 
@@ -87,6 +87,7 @@ def load():
                                         ctypes.POINTER(vp)]
     lib.qnn_free_weights.argtypes = [vp]
     lib.qnn_weights_dequant.argtypes = [vp, vp, vp]
+    lib.qnn_weights_check.argtypes = [vp, vp]
     lib.qnn_conv2d_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
     lib.qnn_dense_forward.argtypes = [vp, vp, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
     lib.qnn_conv2d_workspace_bytes.argtypes = [vp, ci, ci, ci]
@@ -146,6 +147,17 @@ def require_cuda(t, what):
         raise QnnError("%s: tensor is on %s; the low-bit engine has no CPU path" % (what, t.device))
     if t.dtype != torch.float32:
         raise TypeError("%s: expected float32, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+def require_cuda_u8(t, what):
+    """Typed image input (QNN_STORE_U8): a uint8 NHWC CUDA tensor, value = code / 255 (utils/load_data.py:40)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s: expected a torch.Tensor, got %r" % (what, type(t)))
+    if not t.is_cuda:
+        raise QnnError("%s: tensor is on %s; the low-bit engine has no CPU path" % (what, t.device))
+    if t.dtype != torch.uint8:
+        raise TypeError("%s: expected uint8 image bytes, got %s" % (what, t.dtype))
     return t.contiguous()
 
 
@@ -211,6 +223,7 @@ class Weights:
             kh, kw, cin, cout = kernel.shape
         bias = require_cuda(bias, "prepack bias") if bias is not None else None
         self.shape = (kh, kw, cin, cout)
+        self.wkind = wkind
         self.store = store
         self.stride = stride
         self.same_pad = same_pad
@@ -220,6 +233,11 @@ class Weights:
                                          stream_ptr(), ctypes.byref(self.handle)),
               "qnn_prepack_weights")
         self.device = kernel.device
+
+    def check(self):
+        """qnn_weights_check: synchronise the current stream and raise QnnError if a restricted-domain kernel of this
+        layer (the opt-in fixed-point first layer: inputs in [0, 1]) met a value outside its domain since the last check."""
+        check(load().qnn_weights_check(self.handle, stream_ptr()), "qnn_weights_check")
 
     def dequant(self):
         kh, kw, cin, cout = self.shape

@@ -62,6 +62,8 @@ struct qnn_weights {
     uint8_t* d_mfma;      // int8 image [cout][kh*kw][cin] for the MFMA kernel (may alias d_packed)
     void* d_mfma_own;     // owned allocation behind d_mfma (I4 store), or nullptr
     void* d_aux;          // ternary: the 0.7*mean|W| cutoff (1 float), else nullptr
+    uint32_t* h_flag;     // domain flag (pinned, device-visible host word; qnn_weights_check) or nullptr
+    uint32_t* d_flag;     // the same word through the device's address space
 };
 
 struct ConvGeom;
@@ -74,6 +76,8 @@ int qnn_try_launch_stem(const ConvGeom& g, const EpiArgs& e, const void* x, cons
 int qnn_option(int which);
 int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                                hipStream_t s);
+int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
+                            hipStream_t s);
 enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_FIRST_FIXED = 2, QNN_OPT_COUNT = 4 };
 
 // ---- division by a launch-constant via multiply-high (dividends < 2^31) ----------
@@ -113,7 +117,7 @@ struct EpiArgs {
     const float* bias;         // or nullptr
     const float* bn_inv;       // or nullptr
     const float* bn_shift;
-    float scale;               // 2^-(wshift+xshift)
+    float scale;               // 2^-(wshift+xshift); QNN_STORE_U8 input: the divisor 255 * 2^wshift
     float act_m;               // 2^(act_bits-1) for quantized_tanh
     int fn;
     int out_store;
@@ -239,6 +243,25 @@ __device__ __forceinline__ float qnn_epi_residual(float v, long q, int c, const 
         r = __fmul_rn((float)code, e.res_scale);
     }
     return __fmul_rn(__fadd_rn(r, v), e.post_scale);
+}
+// ---- QNN_STORE_U8 input: the affine map behind the exact integer sum (qnn_abi.h, qnn_conv2d_forward) ----
+struct U8Affine {
+    float A, B;
+};
+__device__ __forceinline__ U8Affine qnn_u8_affine(const EpiArgs& e, int c) {
+    const double inv = e.bn_inv ? (double)e.bn_inv[c] : 1.0, shift = e.bn_inv ? (double)e.bn_shift[c] : 0.0;
+    const double bias = e.bias ? (double)e.bias[c] : 0.0;
+    const double m = e.fn == QNN_FN_QUANTIZED_TANH ? (double)e.act_m : 1.0;
+    U8Affine a;
+    a.A = (float)(inv * m / (double)e.scale);
+    a.B = (float)((bias * inv + shift) * m);
+    return a;
+}
+// t = fma(S, A, B) -> what is pooled: the integer code (quantized_tanh), +-1 (binary_tanh), or t itself
+__device__ __forceinline__ float qnn_u8_value(float t, const EpiArgs& e) {
+    if (e.fn == QNN_FN_BINARY_TANH) return t > 0x1p-24f ? 1.0f : -1.0f;
+    if (e.fn == QNN_FN_QUANTIZED_TANH) return fminf(fmaxf(rintf(t), -e.act_m), e.act_m - 1.0f);
+    return t;
 }
 // value -> stored code (BIN: 0/1; I4/I8: signed code) or float bits
 __device__ __forceinline__ int qnn_epi_code(float v, const EpiArgs& e) {

@@ -164,6 +164,24 @@ __device__ float conv_point(const ConvGeom& g, int x_store, const void* __restri
         }
         return acc;
     }
+    if (x_store == QNN_STORE_U8) {
+        // image bytes x integer weight codes (scale = 255 * 2^wshift): the exact integer S, as a float (|S| < 2^24)
+        const uint8_t* xb = (const uint8_t*)x;
+        const float wscale = scale * (1.0f / 255.0f);            // 2^wshift, exact
+        int acc = 0;
+        for (int dy = 0; dy < g.kh; ++dy) {
+            const int iy = oy * g.stride + dy - g.pt;
+            if ((unsigned)iy >= (unsigned)g.H) continue;
+            for (int dx = 0; dx < g.kw; ++dx) {
+                const int ix = ox * g.stride + dx - g.pl;
+                if ((unsigned)ix >= (unsigned)g.W) continue;
+                const uint8_t* a = xb + (((size_t)n * g.H + iy) * g.W + ix) * g.cin;
+                const float* w = wq + ((size_t)c * g.kh * g.kw + dy * g.kw + dx) * g.cin;
+                for (int ci = 0; ci < g.cin; ++ci) acc += (int)a[ci] * (int)rintf(__fmul_rn(w[ci], wscale));
+            }
+        }
+        return (float)acc;
+    }
     const uint32_t* xa = (const uint32_t*)x;
     int acc = 0;
     for (int dy = 0; dy < g.kh; ++dy) {
@@ -205,7 +223,32 @@ __global__ __launch_bounds__(kBlock) void k_conv_generic(ConvGeom g, EpiArgs e, 
         const int px = (int)(q % g.Wp);
         const int py = (int)((q / g.Wp) % g.Hp);
         const int n = (int)(q / ((size_t)g.Wp * g.Hp));
-        if (e.out_store == QNN_STORE_F32) {
+        if (x_store == QNN_STORE_U8) {
+            // typed image input: one FMA behind the exact integer sum (qnn_abi.h, qnn_conv2d_forward)
+            const int bits = e.out_store == QNN_STORE_F32 ? 32 : 32 / pw;
+            uint32_t word = 0;
+            for (int b = 0; b < (e.out_store == QNN_STORE_F32 ? 1 : pw); ++b) {
+                const int c = e.out_store == QNN_STORE_F32 ? slot : slot * pw + b;
+                if (c >= g.cout) break;
+                const U8Affine af = qnn_u8_affine(e, c);
+                float best = 0.0f;
+                for (int s = 0; s < g.pool * g.pool; ++s) {
+                    const int oy = py * g.pool + s / g.pool, ox = px * g.pool + s % g.pool;
+                    const float t = __fmaf_rn(conv_point(g, x_store, x, wp, wq, e.scale, n, oy, ox, c), af.A, af.B);
+                    const float v = qnn_u8_value(t, e);          // code (quantized_tanh), +-1 (binary_tanh) or t
+                    best = (s == 0) ? v : fmaxf(best, v);
+                }
+                if (e.out_store == QNN_STORE_F32) {
+                    if (e.fn == QNN_FN_QUANTIZED_TANH)
+                        best = __fmul_rn(best, __uint_as_float(0x7F000000u - __float_as_uint(e.act_m)));
+                    ((float*)y)[i] = best;
+                } else {
+                    const int code = e.out_store == QNN_STORE_BIN ? (best > 0.0f ? 1 : 0) : (int)best;
+                    word |= ((uint32_t)code & ((1u << bits) - 1u)) << (b * bits);
+                }
+            }
+            if (e.out_store != QNN_STORE_F32) ((uint32_t*)y)[i] = word;
+        } else if (e.out_store == QNN_STORE_F32) {
             const int c = slot;
             float best = 0.0f;
             for (int s = 0; s < g.pool * g.pool; ++s) {
@@ -1091,6 +1134,16 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     int xshift = 0;
     if (x_store == QNN_STORE_F32) {
         // any float32 values; uses the float32 copy of the quantized kernel
+    } else if (x_store == QNN_STORE_U8) {
+        // image bytes, value = code / 255: exact integer sum against the weight CODES (float32 copy * 2^wshift)
+        QNN_REQUIRE(!dense, QNN_EUNSUPPORTED, "dense_forward: no QNN_STORE_U8 input");
+        QNN_REQUIRE(w->wkind == QNN_W_BINARY || w->wkind == QNN_W_TERNARY || (w->wkind == QNN_W_QUANT && w->wbits <= 8),
+                    QNN_EUNSUPPORTED, "conv_forward: QNN_STORE_U8 input needs low-bit weights of <= 8 bits (wkind=%d wbits=%d)",
+                    w->wkind, w->wbits);
+        QNN_REQUIRE(w->H == 1.0f || w->wkind == QNN_W_QUANT, QNN_EUNSUPPORTED, "conv_forward: QNN_STORE_U8 input needs H = 1");
+        QNN_REQUIRE(!epi->res, QNN_EUNSUPPORTED, "conv_forward: no residual input behind a QNN_STORE_U8 layer");
+        QNN_REQUIRE((double)w->kh * w->kw * w->cin * 255.0 * (double)(1 << w->wshift) < 16777216.0, QNN_EUNSUPPORTED,
+                    "conv_forward: QNN_STORE_U8 sums of this layer exceed 2^24");
     } else {
         QNN_REQUIRE(x_store == w->store, QNN_EINVAL,
                     "conv_forward: x_store=%d but the weights were prepacked for store=%d",
@@ -1121,6 +1174,15 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     int rc = check_epilogue(w, epi, xshift, &e);
     if (rc != QNN_OK) return rc;
     if (x_store == QNN_STORE_F32) e.scale = 1.0f;   // d_wq holds real values already
+    if (x_store == QNN_STORE_U8) e.scale = 255.0f * (float)(1 << w->wshift);   // the divisor D of the affine map
+    // a restricted-domain kernel (first_fixed) saw a value outside its domain in an earlier launch of this layer, and
+    // the flag has reached the host: report it now (qnn_weights_check is the synchronising form)
+    if (w->h_flag && *(volatile uint32_t*)w->h_flag) {
+        *(volatile uint32_t*)w->h_flag = 0;
+        qnn_set_error("conv_forward: an earlier launch of this layer (first_fixed) met inputs outside [0, 1]; its "
+                      "outputs are unspecified.  Use the exact first layer or QNN_STORE_U8 input");
+        return QNN_EINVAL;
+    }
     if (N == 0) return QNN_OK;
 
     hipStream_t s = (hipStream_t)stream;
@@ -1149,6 +1211,20 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     if (!launched && !dense && x_store == QNN_STORE_I4 && try_launch_pw_f32(g, e, x, w, y, s) == 0) {
         launched = true;
         snprintf(name, sizeof(name), "pw_i4_f32");
+    }
+    if (x_store == QNN_STORE_U8) {
+        if (pref != 1 && qnn_try_launch_first_u8(g, e, x, w, y, s) == 0) {
+            qnn_set_kernel_name("mfma_i8_first_u8");
+        } else {
+            const size_t total = (size_t)g.N * g.Hp * g.Wp * e.ocw;
+            size_t blocks = (total + kBlock - 1) / kBlock;
+            if (blocks > 65535u * 16u) blocks = 65535u * 16u;
+            hipLaunchKernelGGL(k_conv_generic, dim3((unsigned)blocks), dim3(kBlock), 0, s, g, e, x_store,
+                               x, w->d_packed, w->d_wq, y);
+            qnn_set_kernel_name("generic_u8");
+        }
+        QNN_HIP(hipGetLastError());
+        return QNN_OK;
     }
     if (!launched && pref != 1 && !dense && x_store == QNN_STORE_F32 && qnn_try_launch_stem(g, e, x, w->d_wq, y, s) == 0) {
         launched = true;                           // float-input layer with few filters (ResNet stem)
@@ -1236,6 +1312,12 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
         }                                                                      \
     } while (0)
     PREPACK_HIP(hipMalloc(&w->d_wq, nq * sizeof(float)));
+    if (store == QNN_STORE_F32 && kh == 3 && kw == 3 && cin == 3 && cout == 64) {
+        // domain flag of the restricted-domain first-layer kernel: one word of pinned host memory the device can write
+        PREPACK_HIP(hipHostMalloc((void**)&w->h_flag, sizeof(uint32_t), hipHostMallocMapped));
+        *w->h_flag = 0;
+        PREPACK_HIP(hipHostGetDevicePointer((void**)&w->d_flag, w->h_flag, 0));
+    }
     int grid = (int)((nq + kBlock - 1) / kBlock);
     if (grid > 4096) grid = 4096;
     if (wkind == QNN_W_TERNARY) {
@@ -1287,7 +1369,20 @@ extern "C" int qnn_free_weights(qnn_weights_t* w) {
     if (w->d_corr) (void)hipFree(w->d_corr);
     if (w->d_mfma_own) (void)hipFree(w->d_mfma_own);
     if (w->d_aux) (void)hipFree(w->d_aux);
+    if (w->h_flag) (void)hipHostFree(w->h_flag);
     delete w;
+    return QNN_OK;
+}
+
+extern "C" int qnn_weights_check(const qnn_weights_t* w, void* stream) {
+    QNN_REQUIRE(w, QNN_EINVAL, "qnn_weights_check: null weights");
+    QNN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (w->h_flag && *(volatile uint32_t*)w->h_flag) {
+        *(volatile uint32_t*)w->h_flag = 0;
+        qnn_set_error("qnn_weights_check: a launch of this layer (first_fixed) met inputs outside [0, 1] (or NaN); its "
+                      "outputs are unspecified.  Use the exact first layer or QNN_STORE_U8 input");
+        return QNN_EINVAL;
+    }
     return QNN_OK;
 }
 

@@ -31,9 +31,10 @@ constexpr int kPlane = 4 * kRowPitch;         // words per digit plane (ring of 
 constexpr int kWaveLds = 3 * kPlane;          // words per wave
 
 // x -> the three offset digits of X = rint(x * 2^23) as one word: byte j = (digit j of X) - 128 as a signed byte
-__device__ __forceinline__ uint32_t to_digits(float x) {
+__device__ __forceinline__ uint32_t to_digits(float x, bool& bad) {
+    bad |= !(x >= 0.0f && x <= 1.0f);                             // outside the domain (NaN included): reported, see below
     const int X = (int)rintf(__fmul_rn(x, 8388608.0f));
-    return (uint32_t)min(max(X, 0), 8388608) ^ 0x00808080u;       // inputs outside [0, 1] saturate
+    return (uint32_t)min(max(X, 0), 8388608) ^ 0x00808080u;
 }
 constexpr int kDigitBias = 128 * (1 + 256 + 65536);              // sum_j 128 * 2^(8j)
 
@@ -42,7 +43,8 @@ template <int OUT, int POOL, bool BIN>
 __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs e, const float* __restrict__ x,
                                                               const float* __restrict__ wq, void* __restrict__ y,
                                                               int ntasks, int spr, FastDiv fd_spr, int nch, FastDiv fd_nch,
-                                                              int rc, uint32_t img_x, float wscale, float vscale, float rvscale) {
+                                                              int rc, uint32_t img_x, float wscale, float vscale, float rvscale,
+                                                              uint32_t* __restrict__ domain_flag) {
     extern __shared__ __attribute__((aligned(16))) char smem_fx[];
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, kq = lane >> 4;
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs
     const int st0 = e0row * (kRowPitch * 4) + e0px * 4 + e0ch;           // + slot * 160 (+ plane * 640)
     const int st1 = e1ok ? kRowPitch * 4 + e1px * 4 + e1ch : kRowPitch * 4 + 30 * 4;     // pixel 30 of a row is never read
     const int rowf = g.W * 3 * 4;                                // bytes per input row
+    bool bad = false;                                            // this lane staged a value outside [0, 1]
 
     for (int task = wid; task < ntasks; task += nw) {
         const uint32_t rest = qnn_div((uint32_t)task, fd_nch);
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs
         // rows `row`, `row + 1` into the ring slots SLOT, SLOT + 1
         auto stage_write = [&](auto slotc, float f0, float f1) {
             constexpr int SB = decltype(slotc)::value * (kRowPitch * 4);
-            const uint32_t d0 = to_digits(f0), d1 = to_digits(f1);
+            const uint32_t d0 = to_digits(f0, bad), d1 = to_digits(f1, bad);
             ldsb[st0 + SB] = (uint8_t)d0; ldsb[st0 + SB + kPlane * 4] = (uint8_t)(d0 >> 8);
             ldsb[st0 + SB + 2 * kPlane * 4] = (uint8_t)(d0 >> 16);
             ldsb[st1 + SB] = (uint8_t)d1; ldsb[st1 + SB + kPlane * 4] = (uint8_t)(d1 >> 8);
@@ -241,6 +244,10 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs
         }
         if (rp < rp1) step(std::integral_constant<int, 0>{}, rp);
     }
+    // The domain is part of this kernel's contract: a value outside [0, 1] was clamped above, so the outputs it reaches
+    // are not the layer's.  Raise the layer's flag (a host-visible word inside the weights handle) instead of staying
+    // silent; qnn_weights_check() / the next qnn_conv2d_forward turn it into QNN_EINVAL.
+    if (bad) *domain_flag = 1u;
 }
 
 }  // namespace
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs
 int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                                hipStream_t s) {
     if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.cin != 3 || g.cout != 64 || e.res) return 1;
-    if ((g.W % 16) != 0 || (g.H % 2) != 0 || !w->d_wq) return 1;
+    if ((g.W % 16) != 0 || (g.H % 2) != 0 || !w->d_wq || !w->d_flag) return 1;    // no flag word, no restricted-domain kernel
     // weight codes = value * 2^wshift: binary (+-1, H = 1) or quantized to <= 4 bits (|code| <= 8)
     if (w->wkind == QNN_W_BINARY ? (w->H != 1.0f || w->wshift != 0)
                                : (w->wkind != QNN_W_QUANT || w->wshift < 1 || w->wshift > 3)) return 1;
@@ -285,7 +292,7 @@ int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* 
 #define FIXED_LAUNCH(OUT_, POOL_, BIN_)                                                                                   \
     hipLaunchKernelGGL((k_conv_first_fixed<OUT_, POOL_, BIN_>), grid, block, lds, s, g, e, (const float*)x, w->d_wq, y,    \
                        (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc, \
-                       (uint32_t)img_x, wscale, vscale, 1.0f / vscale)
+                       (uint32_t)img_x, wscale, vscale, 1.0f / vscale, w->d_flag)
     if (!fused) FIXED_LAUNCH(QNN_STORE_F32, 1, false);
     else if (e.fn == QNN_FN_BINARY_TANH) FIXED_LAUNCH(QNN_STORE_I4, 2, true);
     else FIXED_LAUNCH(QNN_STORE_I4, 2, false);

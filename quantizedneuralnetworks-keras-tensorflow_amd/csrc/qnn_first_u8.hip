@@ -1,0 +1,280 @@
+// First layer on the dataset's own bytes: x_store = QNN_STORE_U8, value = code / 255 (utils/load_data.py:40 forms the
+// reference's float32 images exactly so).  Dispatch: conv_forward (qnn_conv.hip); any other shape with U8 input takes
+// k_conv_generic, which implements the same arithmetic.
+//
+// With the integer weight codes k = w * 2^wshift the layer is an INTEGER problem with one offset:
+//     s = code - 128  (one XOR with 0x80: a signed byte),     sum_k k s  +  128 sum_k k  =  sum_k k code  =  S
+// -- ONE pass of v_mfma_i32_16x16x64_i8 per 16 positions x 16 filters.  A zero-padding tap is code 0, i.e. the byte
+// -128, so the halo converts like any other pixel and sum_k k runs over all 27 taps regardless of the border: the
+// constant 128 sum k is produced by the MFMA itself, in the K-block a 3x3x(3+1) window leaves empty (A bytes -128 from a
+// constant LDS block, B bytes summing to -sum k).  The accumulator IS S.
+// Everything the launch fuses behind the sum is one float32 FMA per value, t = fma(S, A[c], B[c]) (qnn_abi.h,
+// qnn_conv2d_forward): the three digit passes, the 64 shift-adds and the four-rounding epilogue of the float-input
+// fixed-point variant (qnn_first_fixed.hip) are gone, and the input is a quarter of the bytes.
+//
+// Layout (as qnn_first_fixed.hip): a wave walks a strip of 16 conv columns down the image two conv rows at a time.
+// MFMA rows = 16 positions = 4 pool windows x (2 x 2), columns = 16 filters, K-block kq = tap row dy: 3 taps x
+// (3 channels + 1 pad byte) + 4 bytes meeting zero weights; K-block 3 = the offset term.  Bytes are staged once
+// (108 per step, two per lane) into a wave-private LDS ring of four input rows of 4-byte pixels.  In the C/D layout a
+// lane holds the four positions of ONE window for one filter: pooling is an in-lane max on the integers (filters of
+// channels with negative BN scale are negated, A[c] with them).
+#include "qnn_mfma_common.h"
+
+namespace {
+
+constexpr int kRowPitchU = 40;                 // words per LDS row (19 pixels touched; 40 == 8 mod 32)
+constexpr int kRingU = 4 * kRowPitchU;         // ring of four input rows
+constexpr int kConstU = kRingU;                // four words 0x80808080: the A operand of K-block 3
+constexpr int kWaveLdsU = kRingU + 4;          // words per wave (a multiple of four: 16-byte aligned)
+
+// (QNN_STORE_I4, 2, BIN): the fused pipeline, quantized_tanh / binary_tanh codes;  (QNN_STORE_F32, 1, false): the layer
+// behind the float32 surface (any fn)
+template <int OUT, int POOL, bool BIN>
+__global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e, const uint8_t* __restrict__ x,
+                                                           const float* __restrict__ wq, void* __restrict__ y,
+                                                           int ntasks, int spr, FastDiv fd_spr, int nch, FastDiv fd_nch,
+                                                           int rc, uint32_t img_x, float wscale, float D) {
+    extern __shared__ __attribute__((aligned(16))) char smem_u8[];
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    uint32_t* lds = reinterpret_cast<uint32_t*>(smem_u8) + wave * kWaveLdsU;
+    uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
+    uint4* tab = reinterpret_cast<uint4*>(smem_u8 + 4 * kWaveLdsU * 4);      // [filter block][lane][2]
+    for (int i = lane; i < kWaveLdsU; i += 64) lds[i] = 0x80808080u;        // code 0 everywhere; the constant block
+
+    // ---- filters: B operand of block nt = filter nt*16 + r, K-block kq.  Wave nt prepares block nt for the workgroup ----
+    {
+        const int c = wave * 16 + r;
+        const float bias = e.bias ? e.bias[c] : 0.0f;
+        const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
+        const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+        const bool flip = POOL == 2 && inv < 0.0f;               // pool with max only: negate the filter and A[c]
+        const float* wrow = wq + (size_t)c * 27 + (kq < 3 ? kq : 2) * 9;
+        int part = 0;
+        uint32_t wd[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int code = (int)rintf(__fmul_rn(wrow[i], wscale));
+            if (flip) code = -code;
+            if (kq == 3) code = 0;
+            part += code;
+            wd[i / 3] |= (uint32_t)(code & 0xFF) << (8 * (i % 3));
+        }
+        part += __shfl_xor(part, 16);                            // sum of the 27 codes of filter c (all four K-block
+        part += __shfl_xor(part, 32);                            // lanes end up with it)
+        if (kq == 3) {
+            // sixteen bytes that sum to -part: against A bytes of -128 they contribute +128 * sum k
+            int rem = -part;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int b = min(max(rem, -127), 127);
+                rem -= b;
+                wd[j >> 2] |= (uint32_t)(b & 0xFF) << (8 * (j & 3));
+            }
+        }
+        // the affine map behind S (qnn_abi.h): float64 from the float32 constants, one rounding each
+        const double m = e.fn == QNN_FN_QUANTIZED_TANH ? (double)e.act_m : 1.0;
+        float A = (float)((double)inv * m / (double)D);
+        const float B = (float)(((double)bias * (double)inv + (double)shift) * m);
+        if (flip) A = -A;
+        tab[(wave * 64 + lane) * 2] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        tab[(wave * 64 + lane) * 2 + 1] = make_uint4(__float_as_uint(A), __float_as_uint(B), 0u, 0u);
+    }
+    __syncthreads();
+    v4i bw[4];
+    float fa[4], fb[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const uint4 t0 = tab[(nt * 64 + lane) * 2], t1 = tab[(nt * 64 + lane) * 2 + 1];
+        bw[nt] = __builtin_bit_cast(v4i, t0);
+        fa[nt] = __uint_as_float(t1.x); fb[nt] = __uint_as_float(t1.y);
+    }
+    LaneEpi ke;
+    lane_epi_init<QNN_STORE_I4>(ke, e, r, r);
+    constexpr int kMagicBits = 0x4B400008;                       // 1.5 * 2^23 + 8: see qnn_mfma_strip.hip
+    const float magic = __int_as_float(kMagicBits);
+    const int code_lo = kMagicBits - (int)e.act_m, code_hi = kMagicBits + (int)e.act_m - 1;
+    // ---- operand addresses (dword index): position m = r: window w = r >> 2, (py, px) = bits of r.  A step works on
+    // conv rows yy0 = 2*rp and yy0 + 1; with rp0 even the ring slot of input row yy0 + py + dy - 1 is
+    // (2*(rp & 1) + py + kq) & 3.  K-block 3 reads the constant block for every tile ----
+    const int py = (r >> 1) & 1, px = r & 1, w = r >> 2;
+    const bool kconst = kq == 3;
+    const int ab0 = kconst ? kConstU : ((py + kq) & 3) * kRowPitchU + 2 * w + px;            // + 8*t, + dx by the 4-dword read
+    const int ab1 = kconst ? kConstU : ((2 + py + kq) & 3) * kRowPitchU + 2 * w + px;
+    const int tstep = kconst ? 0 : 8;
+    // ---- staging: two input rows = 108 bytes per step, elements lane and lane + 64 (lanes >= 44: a dummy pixel) ----
+    const int e0row = lane >= 54 ? 1 : 0, e0rem = lane - 54 * e0row;
+    const int e0px = e0rem / 3, e0ch = e0rem - 3 * e0px;
+    const bool e1ok = lane < 44;
+    const int e1rem = e1ok ? lane + 10 : 0;
+    const int e1px = e1rem / 3, e1ch = e1rem - 3 * e1px;
+    const int st0 = e0row * (kRowPitchU * 4) + e0px * 4 + e0ch;           // + slot * 160
+    const int st1 = e1ok ? kRowPitchU * 4 + e1px * 4 + e1ch : kRowPitchU * 4 + 30 * 4;     // pixel 30 of a row is never read
+    const int rowb = g.W * 3;                                    // bytes per input row
+
+    for (int task = wid; task < ntasks; task += nw) {
+        const uint32_t rest = qnn_div((uint32_t)task, fd_nch);
+        const int chunk = task - (int)rest * nch;
+        const int n = (int)qnn_div(rest, fd_spr);
+        const int xs = ((int)rest - n * spr) * 16;
+        const int rp0 = chunk * rc, rp1 = min(rp0 + rc, g.H / 2);        // rc is even or nch == 1: rp0 is even
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(x) + (size_t)n * img_x, 0, (int)img_x, 0x00020000);
+        // byte offsets of the two staged elements in input row 0 (the row offset is added below); columns outside the
+        // image and, through the per-image descriptor, rows outside it read 0 = code 0
+        // this lane's packed output word of a step (fused form): byte offset inside the image's output, the step's row
+        // goes into the scalar offset of the store -- no per-step address arithmetic on the vector unit
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<uint32_t*>(y) + (size_t)n * g.Hp * g.Wp * e.ocw, 0, g.Hp * g.Wp * e.ocw * 4, 0x00020000);
+        const int ylane = (((xs >> 1) + kq + 4 * ((r & 7) >> 2)) * e.ocw + (r & 3) * 2 + (r >> 3)) * 4;
+        const int yrow = g.Wp * e.ocw * 4;
+        const int c0col = xs - 1 + e0px, c1col = xs - 1 + e1px;
+        const int v0 = (c0col >= 0 && c0col < g.W) ? c0col * 3 + e0ch + e0row * rowb : (int)0x80000000;
+        const int v1 = (e1ok && c1col >= 0 && c1col < g.W) ? c1col * 3 + e1ch + rowb : (int)0x80000000;
+        auto stage_load = [&](int row, uint32_t& b0, uint32_t& b1) {   // rows `row`, `row + 1`
+            const int so = row * rowb;                           // may be negative: the sum wraps out of range
+            b0 = __builtin_amdgcn_raw_buffer_load_b8(xr, v0 + so, 0, 0);
+            b1 = __builtin_amdgcn_raw_buffer_load_b8(xr, v1 + so, 0, 0);
+        };
+        auto stage_write = [&](auto slotc, uint32_t b0, uint32_t b1) {   // into the ring slots SLOT, SLOT + 1
+            constexpr int SB = decltype(slotc)::value * (kRowPitchU * 4);
+            ldsb[st0 + SB] = (uint8_t)(b0 ^ 0x80u);
+            ldsb[st1 + SB] = (uint8_t)(b1 ^ 0x80u);
+        };
+        const int yy_first = 2 * rp0;
+        uint32_t fa0, fa1, fb0, fb1, fc0, fc1;
+        stage_load(yy_first - 1, fa0, fa1);
+        stage_load(yy_first + 1, fb0, fb1);
+        stage_load(yy_first + 3, fc0, fc1);
+        stage_write(std::integral_constant<int, 0>{}, fa0, fa1);         // rows yy_first - 1, yy_first: slots 0, 1
+
+        auto step = [&](auto parc, int rp) {
+            constexpr int PAR = decltype(parc)::value;           // rp & 1
+            const int yy0 = 2 * rp;
+            // rows yy0+1, yy0+2 complete the four rows of this step: slots (yy0 + 2) & 3 and the next
+            stage_write(std::integral_constant<int, PAR ? 0 : 2>{}, fb0, fb1);
+            fb0 = fc0; fb1 = fc1;
+            stage_load(yy0 + 5, fc0, fc1);                       // two steps ahead
+            const uint32_t* abase = lds + (PAR ? ab1 : ab0);
+            v4i A[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t* p = abase + tstep * t;
+                // the 4th dword (the pixel after the three taps) meets zero filter bytes
+                A[t] = __builtin_bit_cast(v4i, make_uint4(p[0], p[1], p[2], p[3]));
+            }
+            // 8 groups (tile t = gq >> 2, filter block nt = gq & 3): the MFMA of group gq + 1 is issued before group gq
+            // is consumed
+            v4i acc[2];
+            int T[8];
+            const v4i z = {0, 0, 0, 0};
+            auto consume = [&](int gq, const v4i& a) {
+                const int t = gq >> 2, nt = gq & 3;
+                if constexpr (POOL == 2) {
+                    T[gq] = max(max(a[0], a[1]), max(a[2], a[3]));
+                } else {
+                    // position i of window kq -> conv pixel (yy0 + (i >> 1), xs + 8t + 2kq + (i & 1))
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = nt * 16 + r;
+                        float v = __fmaf_rn((float)a[i], fa[nt], fb[nt]);
+                        if (e.fn == QNN_FN_BINARY_TANH) v = v > 0x1p-24f ? 1.0f : -1.0f;
+                        else if (e.fn == QNN_FN_QUANTIZED_TANH)
+                            v = __fmul_rn(fminf(fmaxf(rintf(v), -e.act_m), e.act_m - 1.0f),
+                                          __uint_as_float(0x7F000000u - __float_as_uint(e.act_m)));
+                        const long q = ((long)n * g.H + yy0 + (i >> 1)) * g.W + xs + 8 * t + 2 * kq + (i & 1);
+                        reinterpret_cast<float*>(y)[q * g.cout + c] = v;
+                    }
+                }
+            };
+            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], bw[0], z, 0, 0, 0);
+#pragma unroll
+            for (int gq = 0; gq < 8; ++gq) {
+                if (gq + 1 < 8)
+                    acc[(gq + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[(gq + 1) >> 2], bw[(gq + 1) & 3], z, 0, 0, 0);
+                consume(gq, acc[gq & 1]);
+            }
+            if constexpr (OUT == QNN_STORE_I4) {
+                // lane (filter r, window kq): value j = 4*t + nt -> after the transpose lane (r & 7) holds the word of
+                // value j = r & 7: pooled pixel (xs/2 + kq + 4*(j >> 2)), channels (j & 3)*16 + (r & 8) .. +7
+                int cb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float u = __fmaf_rn((float)T[j], fa[j & 3], fb[j & 3]);
+                    if constexpr (BIN) {
+                        cb[j] = u > 0x1p-24f ? kMagicBits + 1 : kMagicBits - 1;
+                    } else {
+                        // rint + clamp in one add and one integer median (the low bits of u + magic are rint(u) + 8)
+                        const int bits = __float_as_int(__fadd_rn(u, magic));
+                        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cb[j]) : "v"(bits), "v"(code_lo), "v"(code_hi));
+                    }
+                }
+                // sum_j cb[j] << 4j by Horner: seven v_lshl_add_u32 (the compiler's form was 7 shifts + 5 three-way adds)
+                uint32_t P = (uint32_t)cb[7];
+#pragma unroll
+                for (int j = 6; j >= 0; --j) asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(P) : "v"(P), "v"(cb[j]));
+                P -= (uint32_t)(kMagicBits - 8) * 0x11111111u;
+                const uint32_t Wd = transpose_nib8(P, ke) ^ 0x88888888u;
+                __builtin_amdgcn_raw_buffer_store_b32(Wd, yr, ylane, rp * yrow, 0);
+            }
+        };
+        int rp = rp0;
+        for (; rp + 2 <= rp1; rp += 2) {
+            step(std::integral_constant<int, 0>{}, rp);
+            step(std::integral_constant<int, 1>{}, rp + 1);
+        }
+        if (rp < rp1) step(std::integral_constant<int, 0>{}, rp);
+    }
+}
+
+}  // namespace
+
+// 0 = launched.  3x3, stride 1, SAME, 3 input channels, 64 filters of <= 7 bits (or binary), W % 16 == 0, H even;
+// fused pipeline form (pool 2, int4 codes out) or float32 output without pooling.
+int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
+                            hipStream_t s) {
+    if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.cin != 3 || g.cout != 64 || e.res) return 1;
+    if ((g.W % 16) != 0 || (g.H % 2) != 0 || !w->d_wq) return 1;
+    // weight codes = value * 2^wshift: binary (+-1, H = 1) or quantized to <= 7 bits (|code| <= 64: the negated filter
+    // still fits a signed byte and sixteen bytes hold -sum k)
+    if (w->wkind == QNN_W_BINARY ? (w->H != 1.0f || w->wshift != 0)
+                               : (w->wkind != QNN_W_QUANT || w->wshift < 1 || w->wshift > 6)) return 1;
+    const bool fused = g.pool == 2 && e.out_store == QNN_STORE_I4 &&
+                       ((e.fn == QNN_FN_QUANTIZED_TANH && e.act_m <= 8.0f) || e.fn == QNN_FN_BINARY_TANH);
+    const bool rawf = g.pool == 1 && e.out_store == QNN_STORE_F32 &&
+                      (e.fn == QNN_FN_NONE || e.fn == QNN_FN_QUANTIZED_TANH || e.fn == QNN_FN_BINARY_TANH);
+    if (!fused && !rawf) return 1;
+    const float wscale = (float)(1 << w->wshift);
+    const int spr = g.W / 16;
+    const double img_x = (double)g.H * g.W * 3;
+    if (img_x >= 1.0e9 || (double)g.N * g.Hp * g.Wp * 8.0 >= 2.0e9 * 4) return 1;
+    const int hp2 = g.H / 2;
+    const int bpc = QNN_ENV_INT("QNN_U8_BPC", 4);           // workgroups per CU (experiment builds only)
+    const int blocks_cap = 256 * (bpc >= 1 && bpc <= 5 ? bpc : 4);
+    const long nwaves = (long)blocks_cap * 4;
+    int best_rc = hp2, best_nch = 1;
+    double best_cost = 1e300;
+    for (int rc = 2; rc <= hp2 + 1; rc += 2) {              // even: every chunk starts on an even row pair
+        const int nch = (hp2 + rc - 1) / rc;
+        const long rounds = ((long)g.N * spr * nch + nwaves - 1) / nwaves;
+        const double cost = (double)rounds * (rc + 1.5);
+        if (cost < best_cost) { best_cost = cost; best_rc = rc; best_nch = nch; }
+    }
+    const long ntasks_l = (long)g.N * spr * best_nch;
+    if (ntasks_l >= 2000000000L) return 1;
+    long blocks = (ntasks_l + 3) / 4;
+    if (blocks > blocks_cap) blocks = blocks_cap;
+    const dim3 grid((unsigned)blocks), block(256);
+    const size_t lds = (size_t)4 * kWaveLdsU * 4 + 4 * 64 * 2 * 16;
+#define U8_LAUNCH(OUT_, POOL_, BIN_)                                                                                       \
+    hipLaunchKernelGGL((k_conv_first_u8<OUT_, POOL_, BIN_>), grid, block, lds, s, g, e, (const uint8_t*)x, w->d_wq, y,      \
+                       (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc, \
+                       (uint32_t)img_x, wscale, e.scale)
+    if (!fused) U8_LAUNCH(QNN_STORE_F32, 1, false);
+    else if (e.fn == QNN_FN_BINARY_TANH) U8_LAUNCH(QNN_STORE_I4, 2, true);
+    else U8_LAUNCH(QNN_STORE_I4, 2, false);
+#undef U8_LAUNCH
+    return 0;
+}

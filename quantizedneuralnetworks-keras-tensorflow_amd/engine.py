@@ -100,9 +100,17 @@ def _prepack(op, store, device, stride=1, same_pad=True):
 
 # ---------------------------------------------------------------------------
 class FusedModel:
-    """Packed, fully fused pipeline for sequential specs (models/vgg.py topology)."""
+    """Packed, fully fused pipeline for sequential specs (models/vgg.py topology).
 
-    def __init__(self, spec, device="cuda"):
+    forward(x) takes the images either as float32 NHWC (any values; `first_layer` picks the kernel: "exact" = the
+    float32 FMA chain the oracle evaluates, "fixed" = the opt-in fixed-point variant for inputs in [0, 1], whose
+    domain violations surface through check_domain()) or as uint8 NHWC, the dataset's own bytes (value = code / 255,
+    utils/load_data.py:40): the typed QNN_STORE_U8 entry of the C ABI, an exact integer first layer."""
+
+    def __init__(self, spec, device="cuda", first_layer="exact"):
+        if first_layer not in ("exact", "fixed"):
+            raise ValueError("first_layer must be 'exact' or 'fixed', got %r" % (first_layer,))
+        self.first_layer = first_layer
         self.device = torch.device(device)
         self.steps = []
         self._keep = []
@@ -192,15 +200,26 @@ class FusedModel:
         return groups
 
     def forward(self, x):
-        """x: float32 NHWC CUDA tensor -> float32 (N, classes)."""
-        x = _abi.require_cuda(x, "FusedModel.forward")
+        """x: float32 or uint8 NHWC CUDA tensor -> float32 (N, classes)."""
+        u8 = isinstance(x, torch.Tensor) and x.dtype == torch.uint8
+        x = _abi.require_cuda_u8(x, "FusedModel.forward") if u8 else _abi.require_cuda(x, "FusedModel.forward")
+        if u8 and (self.steps[0]["kind"] != "conv" or self.steps[0]["w"].wkind == _abi.W_FLOAT):
+            raise _abi.QnnError("FusedModel.forward: uint8 images need a low-bit convolution as the first layer")
         N, H, W, _ = x.shape
         cur = x
         log = getattr(self, "kernel_log", None)      # tests: set to a list to record the kernel of every layer
-        for st in self.steps:
+        for si, st in enumerate(self.steps):
             if st["kind"] == "conv":
-                cur, H, W = _abi.conv2d(st["w"], cur, st["x_store"], st["x_bits"], N, H, W, st["inv"],
-                                        st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"])
+                x_store = _abi.STORE_U8 if (u8 and si == 0) else st["x_store"]
+                fixed = si == 0 and not u8 and self.first_layer == "fixed"
+                if fixed:
+                    _abi.set_option("first_fixed", 1)
+                try:
+                    cur, H, W = _abi.conv2d(st["w"], cur, x_store, st["x_bits"], N, H, W, st["inv"],
+                                            st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"])
+                finally:
+                    if fixed:
+                        _abi.set_option("first_fixed", 0)
             else:
                 cur = _abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
                                  st["fn"], st["act_bits"], st["out_store"])
@@ -209,6 +228,11 @@ class FusedModel:
             if st["softmax"]:
                 cur = torch.softmax(cur, dim=-1)
         return cur
+
+    def check_domain(self):
+        """Synchronise the current stream and raise QnnError if the fixed-point first layer met an input outside
+        [0, 1] since the last check (qnn_weights_check).  A no-op for the exact and uint8 entries."""
+        self.steps[0]["w"].check()
 
     __call__ = forward
     predict = forward
@@ -281,7 +305,8 @@ class GraphModel:
         return t.materialize() if isinstance(t, _Virtual) else t
 
     def forward(self, x):
-        x = _abi.require_cuda(x, "GraphModel.forward")
+        x = (_abi.require_cuda_u8(x, "GraphModel.forward") if isinstance(x, torch.Tensor) and x.dtype == torch.uint8
+             else _abi.require_cuda(x, "GraphModel.forward"))
         env = {"input": x}
         skip = set()
         spec = self.spec
@@ -325,7 +350,8 @@ class GraphModel:
                     w = self._get_weights(i, op, _abi.STORE_F32)
                     if kind == "conv":
                         N, H, W, _ = xin.shape
-                        y, _, _ = _abi.conv2d(w, xin, _abi.STORE_F32, 0, N, H, W, inv, shift)
+                        xs = _abi.STORE_U8 if xin.dtype == torch.uint8 else _abi.STORE_F32    # typed image entry
+                        y, _, _ = _abi.conv2d(w, xin, xs, 0, N, H, W, inv, shift)
                     else:
                         y = _abi.dense(w, xin, _abi.STORE_F32, 0, xin.shape[0], inv, shift)
                 env[name] = y
@@ -472,7 +498,9 @@ class ResidualFusedModel:
 
     # ---- evaluation --------------------------------------------------------------
     def forward(self, x):
-        x = _abi.require_cuda(x, "ResidualFusedModel.forward")
+        x = (_abi.require_cuda_u8(x, "ResidualFusedModel.forward")
+             if isinstance(x, torch.Tensor) and x.dtype == torch.uint8
+             else _abi.require_cuda(x, "ResidualFusedModel.forward"))
         memo = {"input": x}
 
         def f32(name):
@@ -501,6 +529,8 @@ class ResidualFusedModel:
                 N, H, W, C = src.shape
                 w = self._weights(ci, _abi.STORE_F32)
                 xin, xs, xb = src.contiguous(), _abi.STORE_F32, 0
+                if src.dtype == torch.uint8:     # the images as bytes: typed QNN_STORE_U8 entry
+                    xs = _abi.STORE_U8
 
             def launch():
                 return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
@@ -513,6 +543,8 @@ class ResidualFusedModel:
                 # bench.py re-issues every launch of one forward for per-kernel timing: the closure keeps the
                 # operands alive; bytes = tensors as stored (input + output + shortcut), SURVEY.md 8d model M1
                 def nbytes(store, pixels, ch):
+                    if store == _abi.STORE_U8:
+                        return pixels * ch
                     return pixels * ch * 4 if store == _abi.STORE_F32 else pixels * _abi.words(store, ch) * 4
                 kh, kw = op["kernel"].shape[:2]
                 b = nbytes(xs, N * H * W, C) + nbytes(out_store, N * Ho * Wo, cout)
@@ -522,7 +554,7 @@ class ResidualFusedModel:
                                          shape=(N, H, W, C, cout, kh, tuple(op.get("strides", (1, 1)))[0],
                                                 "res_" + ("none" if res is None else "packed" if isinstance(res, _Packed) else "f32")),
                                          bytes=b, macs=N * Ho * Wo * kh * kw * C * cout,
-                                         pipe="f32" if xs == _abi.STORE_F32 else "i8"))
+                                         pipe="f32" if xs == _abi.STORE_F32 and "fixed" not in _abi.last_kernel() else "i8"))
             if out_store == _abi.STORE_F32:
                 return y
             return _Packed(y, out_store, bits, (N, Ho, Wo, cout))

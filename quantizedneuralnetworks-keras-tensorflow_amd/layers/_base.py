@@ -278,14 +278,20 @@ class LowBitConv2D(LowBitLayer):
                 _abi.out_hw(w, self.kernel_size[1], self.strides[1], same), self.filters)
 
     def call(self, inputs):
-        x = _abi.require_cuda(inputs, self.name + ".call")
+        u8 = isinstance(inputs, torch.Tensor) and inputs.dtype == torch.uint8
+        x = (_abi.require_cuda_u8(inputs, self.name + ".call") if u8
+             else _abi.require_cuda(inputs, self.name + ".call"))
         if x.dim() != 4 or x.shape[-1] != self.input_dim:
             raise ValueError("Input 0 is incompatible with layer %s: expected axis -1 of input shape "
                              "to have value %d but got shape %s"
                              % (self.name, self.input_dim, tuple(x.shape)))
         N, H, W, C = x.shape
         plan = self._plan()
-        if plan is None:
+        if u8:
+            # the dataset's own image bytes (extension; value = code / 255, utils/load_data.py:40): typed
+            # QNN_STORE_U8 entry, exact integer sum and one rounding (include/qnn_abi.h)
+            y, _, _ = _abi.conv2d(self._weights(_abi.STORE_F32), x, _abi.STORE_U8, 0, N, H, W)
+        elif plan is None:
             y, _, _ = _abi.conv2d(self._weights(_abi.STORE_F32), x, _abi.STORE_F32, 0, N, H, W)
         else:
             store, bits, fn, nb = plan

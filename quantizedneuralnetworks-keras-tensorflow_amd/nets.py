@@ -386,11 +386,15 @@ def load_dataset(dataset, path, architecture="VGG", classes=10):
     return tuple(sets)
 
 
+def synthetic_images_u8(cf, n, seed=0):
+    """uint8 U{0..255} NHWC: the dataset's own bytes (what keras.datasets hands to utils/load_data.py:38)."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (n, cf.dim, cf.dim, cf.channels), dtype=np.uint8)
+
+
 def synthetic_images(cf, n, seed=0):
     """uint8 U{0..255} / 255 as float32 NHWC (utils/load_data.py:40)."""
-    rng = np.random.default_rng(seed)
-    x = rng.integers(0, 256, (n, cf.dim, cf.dim, cf.channels), dtype=np.uint8)
-    return (x.astype(F32) / F32(255)).astype(F32)
+    return (synthetic_images_u8(cf, n, seed).astype(F32) / F32(255)).astype(F32)
 
 
 def spec_from_keras_npz(path, wbits=None, abits=None):

@@ -505,6 +505,43 @@ def gen_layers(out, state, index):
     index["layers"] = cases
 
 
+def gen_first(out, state):
+    """First-layer shapes of the VGG nets (3 -> 64 filters on image bytes / 255): the reference's
+    BinaryConv2D / QuantizedConv2D .build() + .call() under both scalar promotions.  Written to ref_first.npz with its
+    own index and its own generator state, so ref_{ops,layers,models}.npz stay byte-identical.  These are the cases
+    that qualify the three first-layer kernels of the product (exact float32 chain, fixed point, uint8 entry)."""
+    from layers.binary_layers import BinaryConv2D
+    from layers.quantized_layers import QuantizedConv2D
+    rng = np.random.default_rng(20241005)
+    cases = []
+    for kind, cls, extra, shape, use_bias in (("quantized", QuantizedConv2D, {"nb": 4}, (1, 16, 32, 3), True),
+                                              ("quantized", QuantizedConv2D, {"nb": 4}, (1, 16, 32, 3), False),
+                                              ("quantized", QuantizedConv2D, {"nb": 2}, (1, 16, 48, 3), True),
+                                              ("binary", BinaryConv2D, {}, (1, 16, 32, 3), True),
+                                              ("quantized", QuantizedConv2D, {"nb": 3}, (1, 8, 16, 3), False),
+                                              ("quantized", QuantizedConv2D, {"nb": 4}, (1, 34, 16, 3), True)):
+        if True:
+            xu8 = rng.integers(0, 256, shape, dtype=np.uint8)
+            x = (xu8.astype(F32) / 255).astype(F32)                      # utils/load_data.py:40
+            kern = (rng.integers(-32768, 32768, (3, 3, 3, 64)).astype(F32) / F32(32768)).astype(F32)
+            bias = (rng.standard_normal(64) * 0.05).astype(F32)
+            state["provider"] = lambda layer, name, shp, k=kern, b=bias: k if name == "kernel" else b
+            layer = cls(filters=64, kernel_size=(3, 3), strides=(1, 1), padding="same", use_bias=use_bias, H=1., **extra)
+            layer.build((None,) + x.shape[1:])
+            klm = layer.kernel_lr_multiplier
+            assert isinstance(klm, np.float32)
+            tag = "F%02d" % len(cases)
+            out[tag + "_xu8"] = xu8
+            out[tag + "_kernel"] = (kern * F32(32768)).astype(np.int16)
+            if use_bias:
+                out[tag + "_bias"] = bias
+            out[tag + "_y_nep50"] = layer.call(Tensor(x)).a
+            layer.kernel_lr_multiplier = np.float64(klm)                 # numpy-1.x promotion
+            out[tag + "_y_legacy"] = layer.call(Tensor(x)).a
+            cases.append({"tag": tag, "kind": kind, "nb": extra.get("nb"), "use_bias": use_bias, "klm": float(klm)})
+    out["index_json"] = np.frombuffer(json.dumps({"first": cases}).encode(), dtype=np.uint8)
+
+
 class Cf:
     def __init__(self, **kw):
         self.kernel_initializer, self.kernel_regularizer = "he_normal", 1e-4
@@ -645,7 +682,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_ops.npz"), **ops)
     np.savez_compressed(os.path.join(HERE, "ref_layers.npz"), **lay)
     np.savez_compressed(os.path.join(HERE, "ref_models.npz"), **mod)
-    for f in ("ref_ops.npz", "ref_layers.npz", "ref_models.npz"):
+    first = {}
+    gen_first(first, state)
+    np.savez_compressed(os.path.join(HERE, "ref_first.npz"), **first)
+    for f in ("ref_ops.npz", "ref_layers.npz", "ref_models.npz", "ref_first.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
     print(json.dumps({k: (len(v) if isinstance(v, list) else v) for k, v in index.items()}, indent=1))
 

@@ -56,7 +56,7 @@ CHILD = textwrap.dedent(r'''
             assert msg, what + ": no message in qnn_last_error()"
         return msg
 
-    assert lib.qnn_version() == 2
+    assert lib.qnn_version() == 3
     expect(lib.qnn_set_conv_impl(5), EINVAL, "set_conv_impl(5)")
     expect(lib.qnn_set_conv_impl(-1), EINVAL, "set_conv_impl(-1)")
     expect(lib.qnn_set_conv_impl(0), 0, "set_conv_impl(0)")

@@ -113,8 +113,9 @@ def test_fused_codes_match_the_specification_and_rarely_differ_from_the_oracle(c
 
 
 def test_inputs_outside_the_unit_interval_saturate(fixed_first_layer):
-    """The kernel's domain is images / 255; values outside [0, 1] are clamped (the specification's np.clip), so a
-    caller who feeds something else gets a defined result, not wrapped digits."""
+    """The kernel's domain is images / 255; values outside [0, 1] are clamped (the specification's np.clip), so the
+    digits never wrap -- AND the layer's domain flag is raised (tests/test_gpu_u8.py,
+    test_fixed_point_first_layer_reports_inputs_outside_its_domain): the clamped result is not handed out silently."""
     rng, x, op = _case("q4_32", (2, 16, 32, 3), "quantized", 4)
     x = x.copy()
     x[0, :4] = 1.5
@@ -153,7 +154,9 @@ def test_headline_network_with_the_fixed_point_first_layer(fixed_first_layer):
     agree = (got.argmax(1) == want.argmax(1)).mean()
     print("\n[first_fixed] VGG-64 4/4, 256 images: %.1f %% of the logit rows bit-identical to the oracle, "
           "argmax agreement %.2f %%, max |dlogit| %.3g" % (100 * same_rows, 100 * agree, np.abs(got - want).max()))
-    assert agree >= 0.97
+    # measured: every one of the 256 logit rows bit-identical.  One activation code in ~1.4 M sits close enough to a
+    # rounding threshold to differ (test above), so a single differing row is tolerated; the decision never changes
+    assert agree == 1.0 and same_rows >= 255.0 / 256.0, (agree, same_rows)
 
 
 def test_the_switch_is_off_by_default_and_restores_the_exact_kernel():

@@ -49,7 +49,7 @@ def edge_values():
 # ---------------------------------------------------------------------------
 def test_native_library_is_what_runs():
     assert os.path.exists(_abi.lib_path())
-    assert _abi.load().qnn_version() == 2
+    assert _abi.load().qnn_version() == 3
 
 
 def test_binary_tanh_matches_oracle():

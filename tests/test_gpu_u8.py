@@ -1,0 +1,343 @@
+"""The typed image entry of the C ABI (x_store = QNN_STORE_U8: the dataset's bytes, value = code / 255,
+utils/load_data.py:40) and the qualification of the three first-layer kernels against vectors produced by RUNNING
+the reference's own layers / models (tests/golden/ref_first.npz, ref_models.npz).
+
+  exact   csrc/qnn_first.hip         float32 FMA chain on x = code/255 (default for float32 input)
+  fixed   csrc/qnn_first_fixed.hip   opt-in fixed point for float32 inputs in [0, 1] (domain flag, not saturation)
+  u8      csrc/qnn_first_u8.hip      one offset-int8 MFMA pass on the bytes + k_conv_generic for every other shape
+
+Bars: the u8 entry is BIT-EXACT against its specification restated in oracle/qnn_oracle.py (exact integer sum, one
+float32 FMA); all three are within 1e-5 * max(1, |y|) of what the reference's BinaryConv2D / QuantizedConv2D .call()
+returned, their distances to it are printed side by side; on whole reference-built networks every per-layer activation
+code is compared with the reference's trace and the flips are COUNTED (none allowed where none is measured).
+"""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import qnn_amd
+from qnn_amd import _abi, engine, nets
+from oracle import qnn_oracle as O
+import ref_fixtures as R
+from test_gpu_parity import BIN_ACT, Q, _oracle_group, _rand_bn, dev, host
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _run_u8(xu8, op, bn, act, pool, out_store):
+    """qnn_conv2d_forward with x_store = QNN_STORE_U8 (weights prepacked for the float path)."""
+    N, H, W, C = xu8.shape
+    st = tuple(op.get("strides", (1, 1)))
+    w = engine._prepack(op, _abi.STORE_F32, torch.device("cuda"), stride=st[0], same_pad=op.get("padding", "same") == "same")
+    inv = shift = None
+    if bn is not None:
+        i, s = engine.bn_constants(bn)
+        inv, shift = dev(i), dev(s)
+    fn, abits = _abi.FN_NONE, 0
+    if act is not None:
+        fn, abits = engine._act_code(act)
+    y, Ho, Wo = _abi.conv2d(w, dev(xu8), _abi.STORE_U8, 0, N, H, W, inv, shift, fn,
+                            abits if fn == _abi.FN_QUANTIZED_TANH else 0, pool, out_store)
+    kern = _abi.last_kernel()
+    cout = op["kernel"].shape[3]
+    if out_store == _abi.STORE_F32:
+        return host(y), kern
+    out = _abi.unpack(y, N * Ho * Wo, cout, out_store, abits if abits else 1)
+    return host(out).reshape(N, Ho, Wo, cout), kern
+
+
+def _spec_u8(xu8, op, bn, act, pool):
+    y = O.u8_conv_group(xu8, op, bn, act)
+    return O.maxpool2d(y, 2) if pool == 2 else y
+
+
+def _case(name, shape, kind, nb, cout=64, bias=True, k=3, stride=1):
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    xu8 = rng.integers(0, 256, shape, dtype=np.uint8)
+    op = {"op": "conv", "kind": kind, "kernel": rng.uniform(-1, 1, (k, k, shape[3], cout)).astype(F32),
+          "strides": (stride, stride), "padding": "same"}
+    if bias:
+        op["bias"] = (rng.standard_normal(cout) * 0.05).astype(F32)
+    if nb:
+        op["nb"] = nb
+    return rng, xu8, op
+
+
+# name, shape, kind, nb, cout, k, stride, kernel expected
+CASES = [("q4_32", (3, 32, 32, 3), "quantized", 4, 64, 3, 1, "mfma_i8_first_u8"),
+         ("q2_16x48", (2, 16, 48, 3), "quantized", 2, 64, 3, 1, "mfma_i8_first_u8"),
+         ("q3_nobias", (1, 8, 16, 3), "quantized", 3, 64, 3, 1, "mfma_i8_first_u8"),
+         ("q7_16", (2, 16, 16, 3), "quantized", 7, 64, 3, 1, "mfma_i8_first_u8"),
+         ("bin_32", (2, 32, 32, 3), "binary", None, 64, 3, 1, "mfma_i8_first_u8"),
+         ("q4_tall", (5, 66, 16, 3), "quantized", 4, 64, 3, 1, "mfma_i8_first_u8"),
+         ("q4_many", (300, 4, 16, 3), "quantized", 4, 64, 3, 1, "mfma_i8_first_u8"),
+         ("q8_32", (2, 32, 32, 3), "quantized", 8, 64, 3, 1, "generic_u8"),          # |code| up to 128: generic
+         ("q4_stem16", (2, 24, 20, 3), "quantized", 4, 16, 3, 1, "generic_u8"),      # ResNet stem 3 -> 16
+         ("bin_mnist", (3, 28, 28, 1), "binary", None, 64, 3, 1, "generic_u8"),      # MNIST, one channel
+         ("tern_12", (2, 12, 12, 3), "ternary", None, 32, 3, 1, "generic_u8"),
+         ("q4_s2", (2, 15, 17, 3), "quantized", 4, 32, 3, 2, "generic_u8"),
+         ("q4_w24", (2, 30, 24, 3), "quantized", 4, 64, 3, 1, "generic_u8")]         # W % 16 != 0
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_u8_layer_output_is_the_specified_integer_sum_behind_one_fma(case):
+    name, shape, kind, nb, cout, k, stride, want_kernel = case
+    rng, xu8, op = _case(name, shape, kind, nb, cout, bias="nobias" not in name, k=k, stride=stride)
+    got, kern = _run_u8(xu8, op, None, None, 1, _abi.STORE_F32)
+    assert kern == want_kernel
+    np.testing.assert_array_equal(got, _spec_u8(xu8, op, None, None, 1))                  # its specification: bit-exact
+    # against the float32 path's oracle on x = code / 255 (float64 accumulation = the ideal): the 1e-5 contract
+    x = (xu8.astype(F32) / F32(255)).astype(F32)
+    ideal = _oracle_group(x, op, None, None, 1)
+    err = np.abs(got.astype(np.float64) - ideal)
+    assert np.all(err <= 1e-5 * np.maximum(1.0, np.abs(ideal)))
+    # and closer to the real-number convolution of the exact quotients code/255 than float32 inputs can be
+    kc, ws = O.weight_codes(op)
+    real = O.int_conv2d(xu8.astype(np.int64), kc, op["strides"], "same").astype(np.float64) / (255.0 * 2.0 ** ws)
+    if op.get("bias") is not None:
+        real = real + op["bias"].astype(np.float64)
+    assert np.abs(got - real).max() <= 2.0 * np.spacing(F32(np.abs(real).max()))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("act", [Q(4), Q(2), BIN_ACT, None], ids=["a4", "a2", "abin", "none"])
+def test_u8_fused_group_bit_exact_vs_specification(case, act):
+    """conv + BN (both signs of gamma: the negated-filter pooling) + activation + 2x2 max pool, packed and float32 out."""
+    name, shape, kind, nb, cout, k, stride, want_kernel = case
+    rng, xu8, op = _case(name, shape, kind, nb, cout, bias="nobias" not in name, k=k, stride=stride)
+    bn = _rand_bn(rng, cout, k * k * shape[3] * 0.3)
+    Ho, Wo = -(-shape[1] // stride), -(-shape[2] // stride)
+    pools = [1] + ([2] if Ho >= 2 and Wo >= 2 and act is not None else [])
+    for pool in pools:
+        stores = [_abi.STORE_F32]
+        if act is not None:
+            stores.append(_abi.STORE_I4)
+            if act is BIN_ACT and cout % 32 == 0:
+                stores.append(_abi.STORE_BIN)
+        for store in stores:
+            got, kern = _run_u8(xu8, op, bn, act, pool, store)
+            want = _spec_u8(xu8, op, bn, act, pool)
+            np.testing.assert_array_equal(got, want, err_msg="%s pool %d store %d (%s)" % (name, pool, store, kern))
+            if want_kernel == "mfma_i8_first_u8" and ((pool == 2 and store == _abi.STORE_I4) or
+                                                      (pool == 1 and store == _abi.STORE_F32)):
+                assert kern == "mfma_i8_first_u8", (pool, store, kern)
+
+
+def test_u8_extreme_sums_and_constant_images():
+    """All-255 / all-0 images against all-max / all-min weights: the largest |S| the layer can produce, the offset term
+    128 * sum k at its extremes, and every border class of the zero padding."""
+    for kind, nb, fill in (("quantized", 4, 1.0), ("quantized", 4, -1.0), ("quantized", 7, 1.0), ("binary", None, -1.0)):
+        op = {"op": "conv", "kind": kind, "kernel": np.full((3, 3, 3, 64), fill, F32), "strides": (1, 1),
+              "padding": "same", "bias": np.linspace(-1, 1, 64).astype(F32)}
+        if nb:
+            op["nb"] = nb
+        for val in (255, 0, 128, 1):
+            xu8 = np.full((1, 4, 16, 3), val, np.uint8)
+            got, kern = _run_u8(xu8, op, None, None, 1, _abi.STORE_F32)
+            assert kern == "mfma_i8_first_u8"
+            np.testing.assert_array_equal(got, _spec_u8(xu8, op, None, None, 1))
+
+
+def test_u8_rejects_what_it_cannot_compute():
+    rng, xu8, op = _case("q4_32", (1, 16, 16, 3), "quantized", 4)
+    with pytest.raises(_abi.QnnError, match="low-bit weights"):
+        _run_u8(xu8, dict(op, kind="float"), None, None, 1, _abi.STORE_F32)
+    with pytest.raises(_abi.QnnError, match="low-bit weights"):
+        _run_u8(xu8, dict(op, nb=12), None, None, 1, _abi.STORE_F32)
+    w = engine._prepack(op, _abi.STORE_F32, torch.device("cuda"))
+    res = torch.zeros((1, 16, 16, 64), device="cuda")
+    with pytest.raises(_abi.QnnError, match="residual"):
+        _abi.conv2d(w, dev(xu8), _abi.STORE_U8, 0, 1, 16, 16, res=res, res_store=_abi.STORE_F32)
+    with pytest.raises(TypeError, match="float32"):               # only float32 and uint8 images are typed entries
+        engine.FusedModel(nets.build_spec(nets.baseline_config(2), 1))(dev(xu8).to(torch.int32))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole networks through the typed entry
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_vgg_configs_on_uint8_images_bit_exact_vs_specification(idx):
+    cf = nets.baseline_config(idx)
+    spec = nets.build_spec(cf, nets.SEED_BASE + idx)
+    # give half of the first BN's channels a negative scale: the negated-filter pooling of the fused kernel
+    bn0 = [op for op in spec if op["op"] == "bn"][0]
+    bn0["gamma"] = bn0["gamma"].copy()
+    bn0["gamma"][::2] *= -1
+    xu8 = nets.synthetic_images_u8(cf, 64, 99 + idx)
+    m = engine.FusedModel(spec)
+    m.kernel_log = []
+    got = host(m(dev(xu8)))
+    assert m.kernel_log[0] == ("mfma_i8_first_u8" if idx else "generic_u8")
+    want = O.run_spec_u8(spec, xu8)
+    np.testing.assert_array_equal(got, want)
+    # the residual engine fuses the same conv + BN + activation group behind the bytes: same bits
+    got_r = host(engine.ResidualFusedModel(spec)(dev(xu8)))
+    np.testing.assert_array_equal(got_r, want)
+    # distance to the float32-input path on the same images: counted, not assumed
+    x = (xu8.astype(F32) / F32(255)).astype(F32)
+    ref = host(m(dev(x)))
+    rows = int((np.abs(got - ref).max(axis=1) > 0).sum())
+    print("\n[u8 entry] config %d: %d of %d logit rows differ from the float32-input (exact FMA chain) path, max |d| %.3g"
+          % (idx, rows, got.shape[0], np.abs(got - ref).max()))
+    assert (got.argmax(1) == ref.argmax(1)).mean() >= 0.98
+
+
+def test_resnet_on_uint8_images():
+    cf = nets.Config(network_type="full-qnn", wbits=4, abits=4, architecture="RESNET", nres=1, dim=32)
+    spec = nets.build_spec(cf, 3)[:-1]          # logits
+    xu8 = nets.synthetic_images_u8(cf, 4, 3)
+    m = engine.ResidualFusedModel(spec)
+    m.kernel_log = []
+    got = host(m(dev(xu8)))
+    assert m.kernel_log[0] == "generic_u8"
+    np.testing.assert_array_equal(got, O.run_spec_u8(spec, xu8))
+
+
+def test_keras_surface_layer_accepts_image_bytes():
+    rng, xu8, op = _case("q4_32", (2, 32, 32, 3), "quantized", 4)
+    layer = qnn_amd.QuantizedConv2D(64, kernel_size=(3, 3), padding="same", nb=4, H=1.)
+    layer.build((None, 32, 32, 3))
+    layer.set_weights([op["kernel"], op["bias"]])
+    got = host(layer(dev(xu8)))
+    assert got.dtype == np.float32 and _abi.last_kernel() == "mfma_i8_first_u8"
+    np.testing.assert_array_equal(got, _spec_u8(xu8, op, None, None, 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# qualification against the reference's own outputs
+# ---------------------------------------------------------------------------------------------------------------
+def _first_cases():
+    d = np.load(os.path.join(R.GOLD, "ref_first.npz"))
+    return d, json.loads(bytes(d["index_json"]).decode())["first"]
+
+
+@pytest.mark.parametrize("tag", [c["tag"] for c in _first_cases()[1]])
+def test_three_first_layer_kernels_vs_reference_layer_call(tag):
+    """The reference's BinaryConv2D / QuantizedConv2D .build() + .call() on 3 -> 64 first-layer shapes (executed in
+    place by tests/golden/make_fixtures_from_reference.py): each kernel's distance to what the reference returned, in
+    units of the 1e-5 * max(1, |y|) band.  The fixed-point and uint8 kernels may not be further from the reference
+    than the exact float32 chain is (beyond 2 % of the band)."""
+    d, cases = _first_cases()
+    c = [k for k in cases if k["tag"] == tag][0]
+    xu8 = d[tag + "_xu8"]
+    x = (xu8.astype(F32) / F32(255)).astype(F32)
+    op = {"op": "conv", "kind": c["kind"], "kernel": (d[tag + "_kernel"].astype(F32) / F32(32768)).astype(F32),
+          "strides": (1, 1), "padding": "same"}
+    if c["nb"]:
+        op["nb"] = c["nb"]
+    if c["use_bias"]:
+        op["bias"] = d[tag + "_bias"]
+    w = engine._prepack(op, _abi.STORE_F32, torch.device("cuda"))
+    N, H, W, _ = x.shape
+    outs = {}
+    outs["exact"] = host(_abi.conv2d(w, dev(x), _abi.STORE_F32, 0, N, H, W)[0])
+    assert _abi.last_kernel() == "mfma_f32_first_cin3"
+    _abi.set_option("first_fixed", 1)
+    try:
+        outs["fixed"] = host(_abi.conv2d(w, dev(x), _abi.STORE_F32, 0, N, H, W)[0])
+        assert _abi.last_kernel() == "mfma_i8x3_first_fixed"
+    finally:
+        _abi.set_option("first_fixed", 0)
+    w.check()                                                     # images / 255 are inside the fixed kernel's domain
+    outs["u8"] = host(_abi.conv2d(w, dev(xu8), _abi.STORE_U8, 0, N, H, W)[0])
+    assert _abi.last_kernel() == "mfma_i8_first_u8"
+    ratio = {}
+    for prom in ("nep50", "legacy"):
+        ref = d["%s_y_%s" % (tag, prom)]
+        band = 1e-5 * np.maximum(1.0, np.abs(ref.astype(np.float64)))
+        for k, got in outs.items():
+            ratio[(k, prom)] = float((np.abs(got.astype(np.float64) - ref) / band).max())
+    print("\n[first layer vs reference .call()] %s %s nb=%s: max |d| / band  " % (tag, c["kind"], c["nb"])
+          + "  ".join("%s/%s %.3f" % (k[0], k[1], v) for k, v in sorted(ratio.items())))
+    for (k, prom), v in ratio.items():
+        assert v <= 1.0, (k, prom, v)
+        assert v <= ratio[("exact", prom)] + 0.02, (k, prom, v, ratio[("exact", prom)])
+
+
+def _layer_taps(model_cls, spec, xin, **kw):
+    """The fused engines never materialise a layer's activation in float32; their per-layer activation VALUES are
+    recovered by running the engine on every prefix of the spec that ends in an activation (same kernels, same
+    epilogues, float32 instead of packed output)."""
+    outs = {}
+    for i, op in enumerate(spec):
+        if op["op"] == "act" or i == len(spec) - 1:
+            outs[i] = host(model_cls(spec[:i + 1], **kw)(xin))
+    return outs
+
+
+@pytest.mark.parametrize("tag", ["vgg64_fullqnn44", "vgg64_fullbnn", "vgg_fullqnn88_w", "vgg_fullqnn24", "vgg_qbnn",
+                                 "vgg_mnist_fullbnn"])
+@pytest.mark.parametrize("first", ["exact", "fixed", "u8"])
+def test_reference_built_networks_per_layer_codes(tag, first):
+    """Networks built by the reference's own models/vgg.py with per-layer traces: every activation code the fused
+    engine produces is compared with what the reference's layers produced.  Measured flips (each exactly one code
+    step) are printed and bounded by the count the exact-integer oracle itself has against the reference
+    (tests/test_reference_fixtures.py: 166 of 348 160 on the 8-bit net, 0 elsewhere)."""
+    cf, spec, x, y_ref, trace = R.net(tag)
+    xu8 = np.rint(x.astype(np.float64) * 255).astype(np.uint8)
+    assert np.array_equal((xu8.astype(F32) / F32(255)).astype(F32), x)
+    xin = dev(xu8) if first == "u8" else dev(x)
+    kw = {"first_layer": "fixed"} if first == "fixed" else {}
+    act_idx = [i for i, op in enumerate(spec) if op["op"] == "act"]
+    outs_sparse = _layer_taps(engine.FusedModel, spec, xin, **kw)
+    # the trace also lists conv / bn / pool / flatten outputs: only activation outputs are codes, the final op is y
+    flips = total = 0
+    worst = 0.0
+    pairs = dict(R.align_trace(spec, trace))
+    for i in act_idx:
+        cls, kind, val = trace[pairs[i]]
+        assert kind == "codes", (tag, i, cls)
+        g = outs_sparse[i].reshape(val.shape)
+        bad = g != val
+        flips += int(bad.sum())
+        total += val.size
+        if bad.any():
+            step = 2.0 if spec[i]["fn"] == "binary_tanh" else 2.0 ** -(spec[i]["nb"] - 1)
+            worst = max(worst, float(np.abs(g[bad] - val[bad]).max() / step))
+    got = outs_sparse[len(spec) - 1]
+    dl = float(np.abs(got.astype(np.float64) - y_ref).max())
+    print("\n[%s, first layer %s] %d of %d activation codes differ from the reference's trace (worst %.0f step), "
+          "max |dlogit| %.3g" % (tag, first, flips, total, worst, dl))
+    bound = 400 if tag == "vgg_fullqnn88_w" else 0
+    assert flips <= bound and worst <= 1.0, (tag, first, flips, total, worst)
+    if flips == 0:
+        assert np.all(np.abs(got.astype(np.float64) - y_ref) <= 1e-5 * np.maximum(1.0, np.abs(y_ref)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the fixed-point kernel's domain is enforced, not assumed
+# ---------------------------------------------------------------------------------------------------------------
+def test_fixed_point_first_layer_reports_inputs_outside_its_domain():
+    cf = nets.baseline_config(2)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 2)
+    m = engine.FusedModel(spec, first_layer="fixed")
+    x = nets.synthetic_images(cf, 8, 5)
+    m.kernel_log = []
+    m(dev(x))
+    assert m.kernel_log[0] == "mfma_i8x3_first_fixed"
+    m.check_domain()                                              # images / 255: fine
+    for bad in (1.5, -0.25, float("nan"), float("inf")):
+        xb = x.copy()
+        xb[3, 7, 9, 1] = bad
+        m(dev(xb))
+        with pytest.raises(_abi.QnnError, match=r"outside \[0, 1\]"):
+            m.check_domain()
+        m.check_domain()                                          # reported once, then cleared
+    # after the flag became visible, the next forward call on the layer refuses too (no explicit check needed)
+    xb = x.copy()
+    xb[0, 0, 0, 0] = 2.0
+    m(dev(xb))
+    torch.cuda.synchronize()
+    with pytest.raises(_abi.QnnError, match=r"outside \[0, 1\]"):
+        m(dev(x))
+    m(dev(x))
+    m.check_domain()
+    # the exact kernel and the uint8 entry have no restricted domain
+    e = engine.FusedModel(spec)
+    e(dev(xb))
+    e.check_domain()

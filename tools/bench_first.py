@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time the float-input first layer of a BASELINE config on its own (HIP events behind queued launches).
-Env: IDX (baseline config index, default 2), N (batch, default 4096), FIXED=1 (fixed-point variant), QNN_FIRST_ABL (kernel ablations, timing only).
+Env: IDX (baseline config index, default 2), N (batch, default 4096), FIXED=1 (fixed-point variant), U8=1 (typed uint8
+image entry, QNN_STORE_U8), QNN_FIRST_ABL (kernel ablations, experiment builds only).
 Prints one JSON line: kernel tag, us per launch, fraction of the 157.3 TFLOP/s f32 matrix peak."""
 import importlib
 import json
@@ -22,12 +23,13 @@ cf = nets.baseline_config(idx)
 spec = nets.build_spec(cf, nets.SEED_BASE + idx)
 model = engine.FusedModel(spec)
 st = model.steps[0]
-x = torch.as_tensor(nets.synthetic_images(cf, N, 1)).cuda()
+U8 = os.environ.get("U8", "0") == "1"
+x = torch.as_tensor(nets.synthetic_images_u8(cf, N, 1) if U8 else nets.synthetic_images(cf, N, 1)).cuda()
 
 
 def launch():
-    o, _, _ = abi.conv2d(st["w"], x, st["x_store"], st["x_bits"], N, cf.dim, cf.dim, st["inv"], st["shift"],
-                         st["fn"], st["act_bits"], st["pool"], st["out_store"])
+    o, _, _ = abi.conv2d(st["w"], x, abi.STORE_U8 if U8 else st["x_store"], st["x_bits"], N, cf.dim, cf.dim, st["inv"],
+                         st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"])
     return o
 
 
@@ -49,4 +51,5 @@ kh, kw, cin, cout = st["w"].shape
 flops = 2.0 * N * cf.dim * cf.dim * kh * kw * cin * cout
 print(json.dumps({"kernel": abi.last_kernel(), "idx": idx, "N": N, "abl": os.environ.get("QNN_FIRST_ABL", "0"),
                   "us": round(best * 1e3, 2), "TFLOPs": round(flops / best / 1e9, 1),
+                  "GBps": round((x.numel() * x.element_size() + N * (cf.dim // st["pool"]) ** 2 * cout // 2) / best / 1e6, 1),
                   "frac_f32_mfma": round(flops / best / 1e9 / 157.3, 3)}))
