@@ -125,7 +125,12 @@ int         qnn_set_conv_impl(int impl);
  *                        1e-5 contract, but not the float32 FMA chain of the default kernel -- activation codes whose
  *                        pre-activation sits that close to a rounding threshold can differ from the oracle's.
  *                        Inputs outside [0, 1] (NaN included) are NOT silently saturated: the kernel raises the
- *                        layer's domain flag, see qnn_weights_check(). */
+ *                        layer's domain flag, see qnn_weights_check().
+ *   "first_image" (default 0): 1 = the same layers, for float32 inputs that ARE image bytes / 255 (what
+ *                        utils/load_data.py:40 produces), run on the QNN_STORE_U8 kernel: a value x is read as the byte
+ *                        k = rint(255 x) when |255 x - k| <= 2^-15 (every float32 quotient k/255 passes) and raises the
+ *                        domain flag otherwise.  Result = the typed uint8 entry's (see qnn_conv2d_forward): exact
+ *                        integer sum, one float32 FMA.  Takes precedence over "first_fixed". */
 int         qnn_set_option(const char* key, int value);
 
 /* ---- elementwise activation clips on float32 tensors --------------------- */

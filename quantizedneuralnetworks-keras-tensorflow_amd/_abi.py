@@ -267,20 +267,54 @@ def make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res=None, res
 
 
 def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
-           pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0):
-    """Run qnn_conv2d_forward; x is a float32 NHWC tensor or an int32 packed tensor.
-    Returns (y, Hp, Wp): y float32 (N,Hp,Wp,cout) or int32 (N*Hp*Wp, words)."""
+           pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0, out=None):
+    """Run qnn_conv2d_forward; x is a float32 NHWC tensor, a uint8 NHWC tensor or an int32 packed tensor.
+    Returns (y, Hp, Wp): y float32 (N,Hp,Wp,cout) or int32 (N*Hp*Wp, words); `out` = a tensor of that shape to write
+    into instead of a fresh one."""
     kh, kw, cin, cout = w.shape
     Ho = out_hw(H, kh, w.stride, w.same_pad) // pool
     Wo = out_hw(W, kw, w.stride, w.same_pad) // pool
     if out_store == STORE_F32:
-        y = torch.empty((N, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+        shape, dt = (N, Ho, Wo, cout), torch.float32
     else:
-        y = torch.empty((N * Ho * Wo, words(out_store, cout)), dtype=torch.int32, device=x.device)
+        shape, dt = (N * Ho * Wo, words(out_store, cout)), torch.int32
+    if out is None:
+        y = torch.empty(shape, dtype=dt, device=x.device)
+    else:
+        if tuple(out.shape) != shape or out.dtype != dt or not out.is_contiguous() or out.device != x.device:
+            raise QnnError("conv2d: `out` must be a contiguous %s tensor of shape %s on %s" % (dt, shape, x.device))
+        y = out
     epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale)
     check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
                                     ptr(y), stream_ptr()), "qnn_conv2d_forward")
     return y, Ho, Wo
+
+
+class BoundStep:
+    """qnn_conv2d_forward / qnn_dense_forward with everything bound once: a launch is then one foreign call, not a page
+    of Python.  `x` / `y` are the step's static input / output tensors; either pointer can be overridden per call (a
+    pipeline's first step reads the caller's batch in place, its last step writes into the caller's result)."""
+
+    def __init__(self, kind, w, x_store, x_bits, N, H, W, bn_inv, bn_shift, fn, act_bits, pool, out_store, x, y):
+        self._keep = (w, bn_inv, bn_shift, x, y)
+        self._epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store)
+        self._x = x.data_ptr() if x is not None else 0
+        self._y = y.data_ptr() if y is not None else 0
+        lib = load()
+        if kind == "conv":
+            self._fn = lib.qnn_conv2d_forward
+            self._mid = (x_store, x_bits, N, H, W, ctypes.byref(self._epi))
+        else:
+            self._fn = lib.qnn_dense_forward
+            self._mid = (x_store, x_bits, N, ctypes.byref(self._epi))
+        self._h = w.handle
+        self._what = "qnn_%s_forward" % ("conv2d" if kind == "conv" else "dense")
+
+    def __call__(self, stream, x_ptr=None, y_ptr=None):
+        rc = self._fn(self._h, ctypes.c_void_p(x_ptr or self._x), *self._mid, ctypes.c_void_p(y_ptr or self._y),
+                      ctypes.c_void_p(stream))
+        if rc != QNN_OK:
+            check(rc, self._what)
 
 
 def conv2d_f32in(w, x, in_fn, in_bits, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0, pool=1,

@@ -28,6 +28,10 @@ extern "C" int qnn_set_option(const char* key, int value) {
         g_option[QNN_OPT_FIRST_FIXED].store(value ? 1 : 0, std::memory_order_relaxed);
         return QNN_OK;
     }
+    if (key && strcmp(key, "first_image") == 0) {
+        g_option[QNN_OPT_FIRST_IMAGE].store(value ? 1 : 0, std::memory_order_relaxed);
+        return QNN_OK;
+    }
     qnn_set_error("qnn_set_option: unknown key '%s'", key ? key : "(null)");
     return QNN_EINVAL;
 }

@@ -77,8 +77,8 @@ int qnn_option(int which);
 int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                                hipStream_t s);
 int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
-                            hipStream_t s);
-enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_FIRST_FIXED = 2, QNN_OPT_COUNT = 4 };
+                            hipStream_t s, bool f32in);
+enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_FIRST_FIXED = 2, QNN_OPT_FIRST_IMAGE = 3, QNN_OPT_COUNT = 4 };
 
 // ---- division by a launch-constant via multiply-high (dividends < 2^31) ----------
 struct FastDiv {

@@ -1179,8 +1179,9 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     // the flag has reached the host: report it now (qnn_weights_check is the synchronising form)
     if (w->h_flag && *(volatile uint32_t*)w->h_flag) {
         *(volatile uint32_t*)w->h_flag = 0;
-        qnn_set_error("conv_forward: an earlier launch of this layer (first_fixed) met inputs outside [0, 1]; its "
-                      "outputs are unspecified.  Use the exact first layer or QNN_STORE_U8 input");
+        qnn_set_error("conv_forward: an earlier launch of this layer's restricted-domain kernel met inputs outside its "
+                      "domain (first_fixed: [0, 1]; first_image: image bytes / 255); its outputs are unspecified.  Use the "
+                      "exact first layer or QNN_STORE_U8 input");
         return QNN_EINVAL;
     }
     if (N == 0) return QNN_OK;
@@ -1213,7 +1214,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
         snprintf(name, sizeof(name), "pw_i4_f32");
     }
     if (x_store == QNN_STORE_U8) {
-        if (pref != 1 && qnn_try_launch_first_u8(g, e, x, w, y, s) == 0) {
+        if (pref != 1 && qnn_try_launch_first_u8(g, e, x, w, y, s, false) == 0) {
             qnn_set_kernel_name("mfma_i8_first_u8");
         } else {
             const size_t total = (size_t)g.N * g.Hp * g.Wp * e.ocw;
@@ -1379,8 +1380,9 @@ extern "C" int qnn_weights_check(const qnn_weights_t* w, void* stream) {
     QNN_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (w->h_flag && *(volatile uint32_t*)w->h_flag) {
         *(volatile uint32_t*)w->h_flag = 0;
-        qnn_set_error("qnn_weights_check: a launch of this layer (first_fixed) met inputs outside [0, 1] (or NaN); its "
-                      "outputs are unspecified.  Use the exact first layer or QNN_STORE_U8 input");
+        qnn_set_error("qnn_weights_check: a launch of this layer's restricted-domain kernel met inputs outside its domain "
+                      "(first_fixed: [0, 1]; first_image: image bytes / 255; NaN included); its outputs are unspecified.  "
+                      "Use the exact first layer or QNN_STORE_U8 input");
         return QNN_EINVAL;
     }
     return QNN_OK;

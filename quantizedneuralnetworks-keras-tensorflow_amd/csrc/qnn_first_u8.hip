@@ -27,13 +27,27 @@ constexpr int kRingU = 4 * kRowPitchU;         // ring of four input rows
 constexpr int kConstU = kRingU;                // four words 0x80808080: the A operand of K-block 3
 constexpr int kWaveLdsU = kRingU + 4;          // words per wave (a multiple of four: 16-byte aligned)
 
+// F32IN (opt-in, qnn_set_option("first_image", 1)): the same kernel for float32 inputs that ARE image bytes / 255
+// (utils/load_data.py:40).  A staged value x is read as the byte k = rint(255 x) when |255 x - k| <= 2^-15 and
+// 0 <= k <= 255 -- true for every float32 quotient k/255 (the product is off by < 2^-16) -- and raises the layer's
+// domain flag otherwise (qnn_weights_check), exactly like the fixed-point variant.  An accepted x is within 1.5e-7 of
+// k/255, so the result is within 27 * 1.5e-7 + one rounding of the real convolution of the floats: inside the 1e-5
+// contract for anything the check lets through, and the typed entry's exact result for real images.
+__device__ __forceinline__ uint32_t image_byte(float x, bool& bad) {
+    const float t = __fmul_rn(x, 255.0f);
+    const float r = rintf(t);
+    bad |= !(fabsf(__fsub_rn(t, r)) <= 0x1p-15f && t >= -0.25f && t <= 255.25f);     // NaN / inf fail the first test
+    return (uint32_t)(int)fminf(fmaxf(r, 0.0f), 255.0f);
+}
+
 // (QNN_STORE_I4, 2, BIN): the fused pipeline, quantized_tanh / binary_tanh codes;  (QNN_STORE_F32, 1, false): the layer
 // behind the float32 surface (any fn)
-template <int OUT, int POOL, bool BIN>
-__global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e, const uint8_t* __restrict__ x,
+template <int OUT, int POOL, bool BIN, bool F32IN>
+__global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e, const void* __restrict__ x,
                                                            const float* __restrict__ wq, void* __restrict__ y,
                                                            int ntasks, int spr, FastDiv fd_spr, int nch, FastDiv fd_nch,
-                                                           int rc, uint32_t img_x, float wscale, float D) {
+                                                           int rc, uint32_t img_x, float wscale, float D,
+                                                           uint32_t* __restrict__ domain_flag) {
     extern __shared__ __attribute__((aligned(16))) char smem_u8[];
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, kq = lane >> 4;
@@ -112,7 +126,9 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
     const int e1px = e1rem / 3, e1ch = e1rem - 3 * e1px;
     const int st0 = e0row * (kRowPitchU * 4) + e0px * 4 + e0ch;           // + slot * 160
     const int st1 = e1ok ? kRowPitchU * 4 + e1px * 4 + e1ch : kRowPitchU * 4 + 30 * 4;     // pixel 30 of a row is never read
-    const int rowb = g.W * 3;                                    // bytes per input row
+    constexpr int EB = F32IN ? 4 : 1;                            // bytes per input element
+    const int rowb = g.W * 3 * EB;                               // bytes per input row
+    bool bad = false;                                            // F32IN: this lane staged a value off the byte grid
 
     for (int task = wid; task < ntasks; task += nw) {
         const uint32_t rest = qnn_div((uint32_t)task, fd_nch);
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
         const int xs = ((int)rest - n * spr) * 16;
         const int rp0 = chunk * rc, rp1 = min(rp0 + rc, g.H / 2);        // rc is even or nch == 1: rp0 is even
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t*>(x) + (size_t)n * img_x, 0, (int)img_x, 0x00020000);
+            (uint8_t*)const_cast<void*>(x) + (size_t)n * img_x, 0, (int)img_x, 0x00020000);
         // byte offsets of the two staged elements in input row 0 (the row offset is added below); columns outside the
         // image and, through the per-image descriptor, rows outside it read 0 = code 0
         // this lane's packed output word of a step (fused form): byte offset inside the image's output, the step's row
@@ -131,15 +147,24 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
         const int ylane = (((xs >> 1) + kq + 4 * ((r & 7) >> 2)) * e.ocw + (r & 3) * 2 + (r >> 3)) * 4;
         const int yrow = g.Wp * e.ocw * 4;
         const int c0col = xs - 1 + e0px, c1col = xs - 1 + e1px;
-        const int v0 = (c0col >= 0 && c0col < g.W) ? c0col * 3 + e0ch + e0row * rowb : (int)0x80000000;
-        const int v1 = (e1ok && c1col >= 0 && c1col < g.W) ? c1col * 3 + e1ch + rowb : (int)0x80000000;
+        const int v0 = (c0col >= 0 && c0col < g.W) ? (c0col * 3 + e0ch) * EB + e0row * rowb : (int)0x80000000;
+        const int v1 = (e1ok && c1col >= 0 && c1col < g.W) ? (c1col * 3 + e1ch) * EB + rowb : (int)0x80000000;
         auto stage_load = [&](int row, uint32_t& b0, uint32_t& b1) {   // rows `row`, `row + 1`
             const int so = row * rowb;                           // may be negative: the sum wraps out of range
-            b0 = __builtin_amdgcn_raw_buffer_load_b8(xr, v0 + so, 0, 0);
-            b1 = __builtin_amdgcn_raw_buffer_load_b8(xr, v1 + so, 0, 0);
+            if constexpr (F32IN) {
+                b0 = __builtin_amdgcn_raw_buffer_load_b32(xr, v0 + so, 0, 0);      // float bits; converted at the write
+                b1 = __builtin_amdgcn_raw_buffer_load_b32(xr, v1 + so, 0, 0);
+            } else {
+                b0 = __builtin_amdgcn_raw_buffer_load_b8(xr, v0 + so, 0, 0);
+                b1 = __builtin_amdgcn_raw_buffer_load_b8(xr, v1 + so, 0, 0);
+            }
         };
         auto stage_write = [&](auto slotc, uint32_t b0, uint32_t b1) {   // into the ring slots SLOT, SLOT + 1
             constexpr int SB = decltype(slotc)::value * (kRowPitchU * 4);
+            if constexpr (F32IN) {
+                b0 = image_byte(__uint_as_float(b0), bad);
+                b1 = image_byte(__uint_as_float(b1), bad);
+            }
             ldsb[st0 + SB] = (uint8_t)(b0 ^ 0x80u);
             ldsb[st1 + SB] = (uint8_t)(b1 ^ 0x80u);
         };
@@ -227,6 +252,9 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
         }
         if (rp < rp1) step(std::integral_constant<int, 0>{}, rp);
     }
+    if constexpr (F32IN) {
+        if (bad) *domain_flag = 1u;          // reported by qnn_weights_check / the next qnn_conv2d_forward, never silent
+    }
 }
 
 }  // namespace
@@ -234,7 +262,8 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
 // 0 = launched.  3x3, stride 1, SAME, 3 input channels, 64 filters of <= 7 bits (or binary), W % 16 == 0, H even;
 // fused pipeline form (pool 2, int4 codes out) or float32 output without pooling.
 int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
-                            hipStream_t s) {
+                            hipStream_t s, bool f32in) {
+    if (f32in && !w->d_flag) return 1;                           // no flag word, no restricted-domain kernel
     if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.cin != 3 || g.cout != 64 || e.res) return 1;
     if ((g.W % 16) != 0 || (g.H % 2) != 0 || !w->d_wq) return 1;
     // weight codes = value * 2^wshift: binary (+-1, H = 1) or quantized to <= 7 bits (|code| <= 64: the negated filter
@@ -248,7 +277,8 @@ int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, 
     if (!fused && !rawf) return 1;
     const float wscale = (float)(1 << w->wshift);
     const int spr = g.W / 16;
-    const double img_x = (double)g.H * g.W * 3;
+    const double img_x = (double)g.H * g.W * 3 * (f32in ? 4 : 1);
+    const float D = 255.0f * wscale;                             // the divisor of the affine map (qnn_abi.h)
     if (img_x >= 1.0e9 || (double)g.N * g.Hp * g.Wp * 8.0 >= 2.0e9 * 4) return 1;
     const int hp2 = g.H / 2;
     const int bpc = QNN_ENV_INT("QNN_U8_BPC", 4);           // workgroups per CU (experiment builds only)
@@ -269,9 +299,16 @@ int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, 
     const dim3 grid((unsigned)blocks), block(256);
     const size_t lds = (size_t)4 * kWaveLdsU * 4 + 4 * 64 * 2 * 16;
 #define U8_LAUNCH(OUT_, POOL_, BIN_)                                                                                       \
-    hipLaunchKernelGGL((k_conv_first_u8<OUT_, POOL_, BIN_>), grid, block, lds, s, g, e, (const uint8_t*)x, w->d_wq, y,      \
-                       (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc, \
-                       (uint32_t)img_x, wscale, e.scale)
+    do {                                                                                                                   \
+        if (f32in)                                                                                                         \
+            hipLaunchKernelGGL((k_conv_first_u8<OUT_, POOL_, BIN_, true>), grid, block, lds, s, g, e, x, w->d_wq, y,        \
+                               (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),  \
+                               best_rc, (uint32_t)img_x, wscale, D, w->d_flag);                                            \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_conv_first_u8<OUT_, POOL_, BIN_, false>), grid, block, lds, s, g, e, x, w->d_wq, y,       \
+                               (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),  \
+                               best_rc, (uint32_t)img_x, wscale, D, w->d_flag);                                            \
+    } while (0)
     if (!fused) U8_LAUNCH(QNN_STORE_F32, 1, false);
     else if (e.fn == QNN_FN_BINARY_TANH) U8_LAUNCH(QNN_STORE_I4, 2, true);
     else U8_LAUNCH(QNN_STORE_I4, 2, false);

@@ -272,22 +272,43 @@ class Model:
     test_resnet.py:63-81), reduced to the inference surface: predict / evaluate / summary /
     set of weights, executing on the fused GPU engines."""
 
-    def __init__(self, cf, spec, device="cuda"):
+    def __init__(self, cf, spec, device="cuda", first_layer="exact", lanes=2):
+        """first_layer: kernel for float32 images ("exact" | "image" | "fixed", engine.FusedModel); uint8 images always
+        take the typed QNN_STORE_U8 entry.  lanes: batches kept in flight by predict() (engine.Pipelined)."""
         from . import engine, _abi
         self.cf, self.spec = cf, spec
         try:
-            self.engine = engine.FusedModel(spec, device)          # chains (VGG)
+            self.engine = engine.FusedModel(spec, device, first_layer=first_layer)     # chains (VGG)
         except _abi.NotFusable:
             self.engine = engine.ResidualFusedModel(spec, device)   # residual / non-fusable topologies
         self.layers = [op for op in spec if op["op"] in ("conv", "dense")]
+        self.lanes = int(lanes)
+        self._pipes = {}
+
+    def pipeline(self, batch_size=4096):
+        """The hipGraph pipeline predict() runs on (engine.Pipelined), one per batch size."""
+        from . import engine
+        if batch_size not in self._pipes:
+            self._pipes[batch_size] = engine.Pipelined(self.engine, lanes=self.lanes, batch_size=batch_size)
+        return self._pipes[batch_size]
 
     def predict(self, x, batch_size=4096):
+        """Keras `model.predict`: images (N, H, W, C) -> outputs (N, classes).
+
+        x may be a numpy array -- uint8 (the dataset's bytes: uploaded as bytes, /255 inside the first layer) or
+        anything else (converted to float32) -- and then a numpy array comes back; or a CUDA tensor (uint8 / float32),
+        already resident in HBM, and then a CUDA tensor comes back without any host synchronisation.  Full batches are
+        replayed from hipGraphs with `lanes` batches in flight; a ragged tail runs eagerly."""
         import torch
-        x = torch.as_tensor(np.ascontiguousarray(x, dtype=F32))
-        outs = []
-        for i in range(0, x.shape[0], batch_size):
-            outs.append(self.engine(x[i:i + batch_size].cuda()).cpu())
-        return torch.cat(outs).numpy()
+        resident = isinstance(x, torch.Tensor) and x.is_cuda
+        if not resident:
+            a = np.asarray(x)
+            a = np.ascontiguousarray(a if a.dtype == np.uint8 else a.astype(F32, copy=False))
+            x = torch.from_numpy(a).cuda()
+        y = self.pipeline(batch_size)(x)
+        if hasattr(self.engine, "check_domain") and getattr(self.engine, "first_layer", "exact") != "exact":
+            self.engine.check_domain()       # restricted-domain first layer: never hand out results unchecked
+        return y if resident else y.cpu().numpy()
 
     def evaluate(self, x, y, batch_size=4096):
         """Top-1 accuracy; y is one-hot (or +-1 hinge targets, utils/load_data.py:84-88) or class ids."""
@@ -334,10 +355,10 @@ class Model:
         print_fn("Total params: %d   engine: %s" % (self.count_params(), type(self.engine).__name__))
 
 
-def build_model(cf, seed=0, device="cuda"):
+def build_model(cf, seed=0, device="cuda", first_layer="exact", lanes=2):
     """model_factory.py:18-72: config -> model (synthetic weights; use spec_from_keras_npz +
     Model(cf, spec) to run an imported checkpoint)."""
-    return Model(cf, build_spec(cf, seed), device)
+    return Model(cf, build_spec(cf, seed), device, first_layer=first_layer, lanes=lanes)
 
 
 def activation_range_probe(model, x, number, limit=63.0, batch_size=256):

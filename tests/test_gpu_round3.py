@@ -62,3 +62,92 @@ def test_padded_shard_rows_stay_out_of_the_ternary_statistics():
     m = engine.ResidualFusedModel(spec)
     x = nets.synthetic_images(cf, 7, 4)
     np.testing.assert_array_equal(host(shard.sharded_forward(m, dev(x), 0, 1)), host(m(dev(x))))
+
+
+@pytest.mark.parametrize("first", ["exact", "image", "fixed", "u8"])
+def test_pipelined_predict_equals_the_eager_path(first):
+    """engine.Pipelined (hipGraph per lane, round-robin streams) is what nets.Model.predict runs on: same bits as the
+    eager engine, for full batches, a ragged tail, repeated calls and every input form."""
+    cf = nets.baseline_config(2)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 2)
+    model = nets.Model(cf, spec, first_layer="exact" if first == "u8" else first, lanes=2)
+    xu8 = nets.synthetic_images_u8(cf, 5 * 64 + 17, 21)
+    x = xu8 if first == "u8" else (xu8.astype(F32) / F32(255)).astype(F32)
+    eager = host(model.engine(dev(x)))
+    if first == "u8":
+        np.testing.assert_array_equal(eager, O.run_spec_u8(spec, xu8))
+    elif first == "exact":
+        np.testing.assert_array_equal(eager[:64], O.run_spec(spec, x[:64], float_conv="device"))
+    elif first == "image":
+        np.testing.assert_array_equal(eager, O.run_spec_u8(spec, xu8))       # recognised as bytes: the uint8 entry's result
+    for rep in range(2):
+        got = model.predict(x, batch_size=64)                                # numpy in, numpy out
+        assert isinstance(got, np.ndarray)
+        np.testing.assert_array_equal(got, eager)
+    xd = dev(x)
+    got = model.predict(xd, batch_size=64)                                   # resident in, resident out
+    assert isinstance(got, torch.Tensor) and got.is_cuda
+    np.testing.assert_array_equal(host(got), eager)
+    np.testing.assert_array_equal(host(model.predict(xd[:40], batch_size=64)), eager[:40])      # smaller than a batch
+    pipe = model.pipeline(64)
+    assert len(pipe.lanes_for(xd[:64])) == 2
+    # three lanes, one lane
+    for lanes in (1, 3):
+        np.testing.assert_array_equal(host(engine.Pipelined(model.engine, lanes=lanes, batch_size=128)(xd)), eager)
+
+
+def test_pipelined_first_layer_domain_is_checked_by_predict():
+    cf = nets.baseline_config(2)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 2)
+    x = nets.synthetic_images(cf, 128, 3)
+    for first in ("image", "fixed"):
+        model = nets.Model(cf, spec, first_layer=first)
+        model.predict(x, batch_size=64)
+        bad = x.copy()
+        bad[70, 3, 3, 0] = 0.5001 if first == "image" else 1.25          # off the byte grid / outside [0, 1]
+        with pytest.raises(_abi.QnnError, match="outside its domain"):
+            model.predict(bad, batch_size=64)
+        model.predict(x, batch_size=64)
+
+
+def test_pipelined_residual_and_ternary_networks():
+    cf = nets.Config(network_type="full-qnn", wbits=4, abits=4, architecture="RESNET", nres=1, dim=32)
+    spec = nets.build_spec(cf, 3)
+    model = nets.Model(cf, spec)
+    assert type(model.engine).__name__ == "ResidualFusedModel"
+    x = nets.synthetic_images(cf, 40, 9)
+    eager = np.concatenate([host(model.engine(dev(x[i:i + 16]))) for i in range(0, 40, 16)])
+    np.testing.assert_array_equal(model.predict(x, batch_size=16), eager)
+    cf, spec = _tnn()
+    model = nets.Model(cf, spec)
+    x = nets.synthetic_images(cf, 48, 2)
+    want = np.concatenate([O.run_spec(spec, x[i:i + 16], float_conv="device") for i in range(0, 48, 16)])
+    np.testing.assert_array_equal(model.predict(x, batch_size=16), want)   # batch statistics per 16-image batch
+
+
+def test_bench_default_line_carries_the_contract_and_the_round3_blocks():
+    """bench.py end to end at a small batch (a subprocess, as the driver runs it): one JSON line with the contract's
+    keys, `roofline`, `cpu_baseline`, the first-layer alternatives, the product-call figure and the targets block."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "512",
+                        "--repeats", "2"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["steps"] == 4 and out["n_gpus"] == 1 and out["config"]["first_layer"] == "image"
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["bound"] in ("hbm", "mfma")
+    assert set(out["first_layer_alternatives"]) == {"exact", "fixed", "u8"}
+    assert all("value" in v for v in out["first_layer_alternatives"].values()), out["first_layer_alternatives"]
+    assert out["first_layer_alternatives"]["u8"]["kernel"] == "mfma_i8_first_u8"
+    assert out["model_predict_resident"]["value"] > 0
+    t = out["targets"]
+    assert t["xnor_m0_hbm_frac"] > 0 and t["int8_mfma_frac"]["layers"] == 8
+    assert set(t["images_per_s"]) == {"vgg64_full_bnn", "vgg_large_full_qnn_w8a8", "imagenet224_resnet10_w4a4"}

@@ -5,6 +5,7 @@ the reference's own layers / models (tests/golden/ref_first.npz, ref_models.npz)
   exact   csrc/qnn_first.hip         float32 FMA chain on x = code/255 (default for float32 input)
   fixed   csrc/qnn_first_fixed.hip   opt-in fixed point for float32 inputs in [0, 1] (domain flag, not saturation)
   u8      csrc/qnn_first_u8.hip      one offset-int8 MFMA pass on the bytes + k_conv_generic for every other shape
+  image   csrc/qnn_first_u8.hip      the same kernel for float32 inputs that are bytes / 255 (opt-in, domain flag)
 
 Bars: the u8 entry is BIT-EXACT against its specification restated in oracle/qnn_oracle.py (exact integer sum, one
 float32 FMA); all three are within 1e-5 * max(1, |y|) of what the reference's BinaryConv2D / QuantizedConv2D .call()
@@ -243,9 +244,16 @@ def test_three_first_layer_kernels_vs_reference_layer_call(tag):
         assert _abi.last_kernel() == "mfma_i8x3_first_fixed"
     finally:
         _abi.set_option("first_fixed", 0)
-    w.check()                                                     # images / 255 are inside the fixed kernel's domain
+    _abi.set_option("first_image", 1)
+    try:
+        outs["image"] = host(_abi.conv2d(w, dev(x), _abi.STORE_F32, 0, N, H, W)[0])
+        assert _abi.last_kernel() == "mfma_i8_first_img255"
+    finally:
+        _abi.set_option("first_image", 0)
+    w.check()                                                     # images / 255 are inside both restricted domains
     outs["u8"] = host(_abi.conv2d(w, dev(xu8), _abi.STORE_U8, 0, N, H, W)[0])
     assert _abi.last_kernel() == "mfma_i8_first_u8"
+    np.testing.assert_array_equal(outs["image"], outs["u8"])      # float32 bytes / 255 recognised as the bytes
     ratio = {}
     for prom in ("nep50", "legacy"):
         ref = d["%s_y_%s" % (tag, prom)]
@@ -272,7 +280,7 @@ def _layer_taps(model_cls, spec, xin, **kw):
 
 @pytest.mark.parametrize("tag", ["vgg64_fullqnn44", "vgg64_fullbnn", "vgg_fullqnn88_w", "vgg_fullqnn24", "vgg_qbnn",
                                  "vgg_mnist_fullbnn"])
-@pytest.mark.parametrize("first", ["exact", "fixed", "u8"])
+@pytest.mark.parametrize("first", ["exact", "fixed", "image", "u8"])
 def test_reference_built_networks_per_layer_codes(tag, first):
     """Networks built by the reference's own models/vgg.py with per-layer traces: every activation code the fused
     engine produces is compared with what the reference's layers produced.  Measured flips (each exactly one code
@@ -282,7 +290,7 @@ def test_reference_built_networks_per_layer_codes(tag, first):
     xu8 = np.rint(x.astype(np.float64) * 255).astype(np.uint8)
     assert np.array_equal((xu8.astype(F32) / F32(255)).astype(F32), x)
     xin = dev(xu8) if first == "u8" else dev(x)
-    kw = {"first_layer": "fixed"} if first == "fixed" else {}
+    kw = {"first_layer": first} if first in ("fixed", "image") else {}
     act_idx = [i for i, op in enumerate(spec) if op["op"] == "act"]
     outs_sparse = _layer_taps(engine.FusedModel, spec, xin, **kw)
     # the trace also lists conv / bn / pool / flatten outputs: only activation outputs are codes, the final op is y
@@ -309,6 +317,37 @@ def test_reference_built_networks_per_layer_codes(tag, first):
         assert np.all(np.abs(got.astype(np.float64) - y_ref) <= 1e-5 * np.maximum(1.0, np.abs(y_ref)))
 
 
+def test_image_mode_recognises_every_byte_and_nothing_else():
+    """first_layer="image": all 256 quotients k/255 (as float32, and one ulp to either side) are read as the byte k;
+    anything further than 2^-15 / 255 from the grid raises the domain flag."""
+    cf = nets.baseline_config(2)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 2)
+    m = engine.FusedModel(spec, first_layer="image")
+    codes = np.arange(256, dtype=np.uint8)
+    xu8 = np.resize(codes, (4, 32, 32, 3)).astype(np.uint8)
+    x = (xu8.astype(F32) / F32(255)).astype(F32)
+    want = O.run_spec_u8(spec, xu8)
+    m.kernel_log = []
+    for xv in (x, np.nextafter(x, F32(2)), np.nextafter(x, F32(-1))):
+        np.testing.assert_array_equal(host(m(dev(xv))), want)
+        m.check_domain()
+    assert m.kernel_log[0] == "mfma_i8_first_img255"
+    for off in (3e-7, -3e-7, 1e-3, 0.5 / 255):
+        xb = x.copy()
+        xb[2, 5, 6, 1] = F32(100.0 / 255.0 + off)
+        m(dev(xb))
+        with pytest.raises(_abi.QnnError, match="outside its domain"):
+            m.check_domain()
+    for bad in (float("nan"), float("inf"), -1.0 / 255, 256.0 / 255):
+        xb = x.copy()
+        xb[0, 0, 0, 0] = bad
+        m(dev(xb))
+        with pytest.raises(_abi.QnnError, match="outside its domain"):
+            m.check_domain()
+    m(dev(x))
+    m.check_domain()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the fixed-point kernel's domain is enforced, not assumed
 # ---------------------------------------------------------------------------------------------------------------
@@ -325,7 +364,7 @@ def test_fixed_point_first_layer_reports_inputs_outside_its_domain():
         xb = x.copy()
         xb[3, 7, 9, 1] = bad
         m(dev(xb))
-        with pytest.raises(_abi.QnnError, match=r"outside \[0, 1\]"):
+        with pytest.raises(_abi.QnnError, match="outside its domain"):
             m.check_domain()
         m.check_domain()                                          # reported once, then cleared
     # after the flag became visible, the next forward call on the layer refuses too (no explicit check needed)
@@ -333,7 +372,7 @@ def test_fixed_point_first_layer_reports_inputs_outside_its_domain():
     xb[0, 0, 0, 0] = 2.0
     m(dev(xb))
     torch.cuda.synchronize()
-    with pytest.raises(_abi.QnnError, match=r"outside \[0, 1\]"):
+    with pytest.raises(_abi.QnnError, match="outside its domain"):
         m(dev(x))
     m(dev(x))
     m.check_domain()

@@ -24,12 +24,25 @@ spec = nets.build_spec(cf, nets.SEED_BASE + idx)
 model = engine.FusedModel(spec)
 st = model.steps[0]
 U8 = os.environ.get("U8", "0") == "1"
-x = torch.as_tensor(nets.synthetic_images_u8(cf, N, 1) if U8 else nets.synthetic_images(cf, N, 1)).cuda()
+if os.environ.get("IMAGE", "0") == "1":          # float32 bytes / 255 recognised as bytes (csrc/qnn_first_u8.hip, F32IN)
+    abi.set_option("first_image", 1)
+# ROTATE=K: K distinct input batches used in turn, so the kernel reads HBM and not a batch that stays in the 256 MB
+# Infinity Cache between launches (one float32 CIFAR batch is 50 MB)
+ROT = int(os.environ.get("ROTATE", "1"))
+xs = [torch.as_tensor(nets.synthetic_images_u8(cf, N, 1 + r) if U8 else nets.synthetic_images(cf, N, 1 + r)).cuda()
+      for r in range(ROT)]
+x = xs[0]
+outb = None
+cnt = [0]
 
 
 def launch():
-    o, _, _ = abi.conv2d(st["w"], x, abi.STORE_U8 if U8 else st["x_store"], st["x_bits"], N, cf.dim, cf.dim, st["inv"],
-                         st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"])
+    global outb
+    xi = xs[cnt[0] % ROT]
+    cnt[0] += 1
+    o, _, _ = abi.conv2d(st["w"], xi, abi.STORE_U8 if U8 else st["x_store"], st["x_bits"], N, cf.dim, cf.dim, st["inv"],
+                         st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"], out=outb)
+    outb = o
     return o
 
 
@@ -49,7 +62,7 @@ for rep in range(5):
     best = min(best, e0.elapsed_time(e1) / 20)
 kh, kw, cin, cout = st["w"].shape
 flops = 2.0 * N * cf.dim * cf.dim * kh * kw * cin * cout
-print(json.dumps({"kernel": abi.last_kernel(), "idx": idx, "N": N, "abl": os.environ.get("QNN_FIRST_ABL", "0"),
+print(json.dumps({"kernel": abi.last_kernel(), "idx": idx, "N": N, "rotate": ROT, "abl": os.environ.get("QNN_FIRST_ABL", "0"),
                   "us": round(best * 1e3, 2), "TFLOPs": round(flops / best / 1e9, 1),
                   "GBps": round((x.numel() * x.element_size() + N * (cf.dim // st["pool"]) ** 2 * cout // 2) / best / 1e6, 1),
                   "frac_f32_mfma": round(flops / best / 1e9 / 157.3, 3)}))
