@@ -72,6 +72,8 @@ def parse_args(argv=None):
                          "default; exact: float32 FMA chain; fixed: fixed point for [0, 1]) or u8 = the bytes themselves "
                          "through the typed QNN_STORE_U8 entry.  The other entries are reported beside the headline")
     ap.add_argument("--no-targets", action="store_true", help="skip the north-star target block (layer ops, other workloads)")
+    ap.add_argument("--no-alternatives", action="store_true",
+                    help="skip the other first-layer entries and the Model.predict figure (profiling runs)")
     ap.add_argument("--rehearse", action="store_true",
                     help="allow more ranks than GPUs (ranks share devices, logits exchanged over gloo)")
     return ap.parse_args(argv)
@@ -235,10 +237,12 @@ def load_traffic(tag, workload):
     """HBM bytes per launch of kernel `tag` from the committed PMC passes of `workload` (profiles/latest_traffic.json:
     one `by_tag` table per profiled workload, written by tools/summarize_profile.py; exact tag match, a tag that
     several profiled kernels share is not listed).  rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; gfx950 FETCH_SIZE
-    counts 64 of every 128 fetched bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled -- except for
-    kernels whose loads are narrow ("other access widths are uncalibrated: calibrate on a known byte count"): the strip
-    kernels (8 and 2 bytes per lane; a 64 x 224^2 x 16 layer with packed shortcut must read between 51.4 MB and 60.4 MB
-    and reports FETCH_SIZE 52.3 MB) and the uint8 first layer (1 byte per lane; 12.6 MB of image bytes): factor 1."""
+    counts 64 of every 128 fetched bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled -- except for the
+    strip kernels, whose loads are 8 and 2 bytes per lane ("other access widths are uncalibrated: calibrate on a known
+    byte count"): a 64 x 224^2 x 16 layer with packed shortcut must read between 51.4 MB and 60.4 MB and reports
+    FETCH_SIZE 52.3 MB, factor 1.  Calibration of the first-layer kernels (profiles/r03): the uint8 entry must read
+    12.58 MB of image bytes and reports 6 223 KiB (x2 = 12.7 MB), the float32 "image" entry 50.3 MB and reports
+    24 660 KiB (x2 = 50.5 MB): factor 2 for byte and dword loads of consecutive lanes alike."""
     path = os.path.join(ROOT, "profiles", "latest_traffic.json")
     try:
         ent = json.load(open(path)).get("by_workload", {}).get(workload, {}).get(tag)
@@ -246,7 +250,7 @@ def load_traffic(tag, workload):
         return None, None
     if not ent or "fetch_kb" not in ent or "write_kb" not in ent:
         return None, None
-    factor = 1.0 if (tag.startswith("strip_") or tag == "mfma_i8_first_u8") else 2.0
+    factor = 1.0 if tag.startswith("strip_") else 2.0
     return (factor * ent["fetch_kb"] + ent["write_kb"]) * 1024.0, ent.get("rocprof_kernel")
 
 
@@ -613,7 +617,7 @@ def main_rank(args):
                          "roof_ms": round(layer_roof_ms(k), 5),
                          **({"shape": list(k["shape"])} if "shape" in k else {})} for k in per_kernel],
         }
-        if world == 1 and fused and lanes and not use_dist:
+        if world == 1 and fused and lanes and not use_dist and not args.no_alternatives:
             # the same workload through the other first-layer entries, same graphs-in-flight scheme and the same number
             # of steps per region (NOT the headline; `config.first_layer` names the one `value` was measured with)
             alts = {}
@@ -636,11 +640,12 @@ def main_rank(args):
                 except Exception as exc:  # pragma: no cover
                     alts[first] = {"error": str(exc)}
             out["first_layer_alternatives"] = alts
-            # the PRODUCT call on resident data: nets.Model.predict on a CUDA tensor of 16 batches (copies every batch
-            # into a lane's static input, replays, copies the logits out; no host synchronisation inside)
+            # the PRODUCT call on resident data: nets.Model.predict on a CUDA tensor of 64 batches (3.2 GB of float32
+            # images, far more than the 256 MB Infinity Cache): engine.Pipelined's bound launch plans read every batch
+            # in place and write the logits in place; the one host synchronisation is predict's domain check at the end
             try:
                 mp = nets.Model(cf, spec, first_layer="exact" if u8 else args.first_layer, lanes=len(lanes))
-                nb = 16
+                nb = 64 if N * cf.dim * cf.dim * cf.channels * 4 * 64 < 8e9 else 8
                 xb = torch.as_tensor(make_input(args.first_layer, N, nets.SEED_BASE + idx)).cuda().repeat(nb, 1, 1, 1)
                 mp.predict(xb, batch_size=N)
                 ts = []

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Where does nets.Model.predict spend its time on a resident tensor?  Host-side enqueue time of the batch loop (no
+synchronisation) against the total, for the bound launch plan and the hipGraph lanes.  Env: FIRST (image|u8|exact|fixed),
+NB (batches, default 64)."""
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+pkg = importlib.import_module("quantizedneuralnetworks-keras-tensorflow_amd")
+nets, engine, abi = pkg.nets, pkg.engine, pkg._abi
+first = os.environ.get("FIRST", "image")
+NB = int(os.environ.get("NB", "64"))
+N = 4096
+cf = nets.baseline_config(2)
+spec = nets.build_spec(cf, nets.SEED_BASE + 2)
+model = engine.FusedModel(spec, first_layer="exact" if first == "u8" else first)
+a = nets.synthetic_images_u8(cf, N, 3)
+x1 = torch.as_tensor(a if first == "u8" else (a.astype(np.float32) / np.float32(255))).cuda()
+xb = x1.repeat(NB, 1, 1, 1)
+pipe = engine.Pipelined(model, lanes=2, batch_size=N)
+pipe(xb[:2 * N])
+torch.cuda.synchronize()
+res = {"first": first, "batches": NB}
+for rep in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    y = pipe(xb)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+res["bound_plan"] = {"enqueue_us_per_batch": round((t1 - t0) / NB * 1e6, 1), "total_us_per_batch": round((t2 - t0) / NB * 1e6, 1),
+                     "Mimg_s": round(NB * N / (t2 - t0) / 1e6, 2)}
+lanes = pipe.lanes_for(x1)
+for rep in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(NB):
+        ln = lanes[i % 2]
+        with torch.cuda.stream(ln["stream"]):
+            ln["graph"].replay()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+res["graph_replay_static_input"] = {"enqueue_us_per_batch": round((t1 - t0) / NB * 1e6, 1),
+                                    "total_us_per_batch": round((t2 - t0) / NB * 1e6, 1),
+                                    "Mimg_s": round(NB * N / (t2 - t0) / 1e6, 2)}
+# one lane only, bound plan: the serial GPU time of a forward launched kernel by kernel
+b = model.bind(x1)
+plan = b[0]
+yy = torch.empty(b[1], dtype=b[2], device="cuda")
+s = torch.cuda.Stream()
+if first in ("image", "fixed"):
+    abi.set_option("first_" + first, 1)
+for rep in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(NB):
+        plan(s.cuda_stream, x1.data_ptr(), yy.data_ptr())
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+res["bound_plan_one_lane"] = {"enqueue_us_per_batch": round((t1 - t0) / NB * 1e6, 1),
+                              "total_us_per_batch": round((t2 - t0) / NB * 1e6, 1)}
+print(json.dumps(res))

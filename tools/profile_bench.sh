@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --inflight 1: kernels of two overlapped batches share the CUs, which would inflate every per-kernel
 # duration; the roofline figures are per kernel, so the profile is taken with one batch in flight
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --inflight 1 $*"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-targets --no-alternatives --inflight 1 $*"
 # 1) kernel trace + stats (timing)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.log 2>&1 || exit 1
 # 2) PMC passes (separate runs, kernel-trace only beside them)
