@@ -24,6 +24,7 @@
 #endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));   // operand pair of the packed float32 VALU operations
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 int qnn_conv_impl_pref();   // 0 auto, 1 valu, 2 mfma (qnn_api.hip)

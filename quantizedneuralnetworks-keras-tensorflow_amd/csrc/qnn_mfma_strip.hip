@@ -87,7 +87,10 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
     const bool binary = e.fn == QNN_FN_BINARY_TANH;
     const float cfold = (RES != 0 ? e.post_scale : 1.0f) * (binary ? 1.0f : e.act_m);
     const float rcoef = RES == 1 ? e.res_scale * cfold : cfold;        // shortcut code (or float value) -> scaled sum
-    float nb[NT][4], ninv[NT][4], nshift[NT][4];
+    // (the float32 steps run on channel PAIRS: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 round each half exactly like
+    // their scalar forms and issue at the same rate -- tools/micro/pk_f32_rate.hip -- so the multiply, the two adds and
+    // the shortcut FMA cost half an instruction per value)
+    v2f nb[NT][2], ninv[NT][2], nshift[NT][2];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -95,14 +98,17 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
             const int c = nbase + nt * 16 + 4 * kq + i;
             const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
             const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
-            nb[nt][i] = BIAS ? __fdiv_rn(e.bias[c], e.scale) : 0.0f;
-            ninv[nt][i] = __fmul_rn(__fmul_rn(inv, e.scale), cfold);
-            nshift[nt][i] = __fmul_rn(shift, cfold);
+            nb[nt][i >> 1][i & 1] = BIAS ? __fdiv_rn(e.bias[c], e.scale) : 0.0f;
+            ninv[nt][i >> 1][i & 1] = __fmul_rn(__fmul_rn(inv, e.scale), cfold);
+            nshift[nt][i >> 1][i & 1] = __fmul_rn(shift, cfold);
         }
+    const v2f rcoef2 = {rcoef, rcoef};
     // round-half-even + clamp + offset code in the integer domain: as_int(u + (1.5*2^23 + 8)) = 0x4B400008 + rint(u)
     // for |u| < 2^22 and is monotone in u everywhere, so a signed integer med3 clamps it; the low nibble is code + 8
     constexpr float kMagic = 12582920.0f;
     constexpr int kMagicBits = 0x4B400008;
+    v2f magic2 = {kMagic, kMagic};
+    asm volatile("" : "+v"(magic2));                  // a register pair (v_pk_add_f32 takes no literal): keeps the add packed
     const int code_lo = kMagicBits - (int)e.act_m, code_hi = kMagicBits + (int)e.act_m - 1;
     const int rowb = g.W * PIXB;                      // bytes per input row
     const int orowb = g.W * e.ocw * 4;                // bytes per output row
@@ -207,33 +213,39 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
             // ---- epilogue: the reference's op order, one rounding per operation ----
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float u4[4];
+                v2f u2[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = (float)acc[nt][i];
-                    if constexpr (BIAS) v = __fadd_rn(v, nb[nt][i]);
-                    float u = __fadd_rn(__fmul_rn(v, ninv[nt][i]), nshift[nt][i]);
+                for (int h = 0; h < 2; ++h) {
+                    v2f v = {(float)acc[nt][2 * h], (float)acc[nt][2 * h + 1]};
+                    if constexpr (BIAS) v = v + nb[nt][h];
+                    v2f u = v * ninv[nt][h];                       // two roundings per value, as the reference's BN
+                    u = u + nshift[nt][h];
                     if constexpr (RES == 1) {
                         // shortcut value = code * 2^-(bits-1), exact: fma(code, scale, t) IS the reference's x + y
-                        const int code = (int)(rcur[nt] << (28 - 4 * i)) >> 28;
-                        u = __fmaf_rn((float)code, rcoef, u);
+                        const v2f cd = {(float)((int)(rcur[nt] << (28 - 8 * h)) >> 28),
+                                        (float)((int)(rcur[nt] << (24 - 8 * h)) >> 28)};
+                        u = __builtin_elementwise_fma(cd, rcoef2, u);
                     }
                     if constexpr (RES == 2) {
-                        const float rv = i == 0 ? fcur[nt].x : i == 1 ? fcur[nt].y : i == 2 ? fcur[nt].z : fcur[nt].w;
-                        u = __fmaf_rn(rv, rcoef, u);              // (x + y) * 2^k == x*2^k + y*2^k, one rounding either way
+                        const v2f rv = h == 0 ? v2f{fcur[nt].x, fcur[nt].y} : v2f{fcur[nt].z, fcur[nt].w};
+                        u = __builtin_elementwise_fma(rv, rcoef2, u);   // (x + y) * 2^k == x*2^k + y*2^k, one rounding either way
                     }
-                    u4[i] = u;
+                    u2[h] = u;
                 }
                 int cb[4];
                 if (binary) {
                     asm volatile("; binary_tanh codes");          // keeps this a real (uniform) branch
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) cb[i] = u4[i] > 0x1p-24f ? kMagicBits + 1 : kMagicBits - 1;
+                    for (int i = 0; i < 4; ++i) cb[i] = u2[i >> 1][i & 1] > 0x1p-24f ? kMagicBits + 1 : kMagicBits - 1;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int bits = __float_as_int(__fadd_rn(u4[i], kMagic));
-                        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cb[i]) : "v"(bits), "v"(code_lo), "v"(code_hi));
+                    for (int h = 0; h < 2; ++h) {
+                        const v2f t = u2[h] + magic2;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int bits = __float_as_int(t[j]);
+                            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cb[2 * h + j]) : "v"(bits), "v"(code_lo), "v"(code_hi));
+                        }
                     }
                 }
                 // low nibble of cb[i] = code + 8, bits 4..21 are zero: three shift-ors assemble the 16-bit field
@@ -303,18 +315,20 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
             }
     const bool binary = e.fn == QNN_FN_BINARY_TANH;
     const float cfold = binary ? 1.0f : e.act_m;
-    float nb[NT][4], ninv[NT][4], nshift[NT][4];
+    v2f nb[NT][2], ninv[NT][2], nshift[NT][2];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = nbase + nt * 16 + 4 * kq + i;
-            nb[nt][i] = BIAS ? __fdiv_rn(e.bias[c], e.scale) : 0.0f;
-            ninv[nt][i] = __fmul_rn(__fmul_rn(e.bn_inv ? e.bn_inv[c] : 1.0f, e.scale), cfold);
-            nshift[nt][i] = __fmul_rn(e.bn_inv ? e.bn_shift[c] : 0.0f, cfold);
+            nb[nt][i >> 1][i & 1] = BIAS ? __fdiv_rn(e.bias[c], e.scale) : 0.0f;
+            ninv[nt][i >> 1][i & 1] = __fmul_rn(__fmul_rn(e.bn_inv ? e.bn_inv[c] : 1.0f, e.scale), cfold);
+            nshift[nt][i >> 1][i & 1] = __fmul_rn(e.bn_inv ? e.bn_shift[c] : 0.0f, cfold);
         }
     constexpr float kMagic = 12582920.0f;
     constexpr int kMagicBits = 0x4B400008;
+    v2f magic2 = {kMagic, kMagic};
+    asm volatile("" : "+v"(magic2));                  // a register pair (v_pk_add_f32 takes no literal): keeps the add packed
     const int code_lo = kMagicBits - (int)e.act_m, code_hi = kMagicBits + (int)e.act_m - 1;
     const int rowb2 = 2 * g.W * PIXB;                  // two input rows per output row
     const int orowb = g.Wo * e.ocw * 4;
@@ -372,23 +386,28 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
                 }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float u4[4];
+                v2f u2[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = (float)acc[nt][i];
-                    if constexpr (BIAS) v = __fadd_rn(v, nb[nt][i]);
-                    u4[i] = __fadd_rn(__fmul_rn(v, ninv[nt][i]), nshift[nt][i]);
+                for (int h = 0; h < 2; ++h) {
+                    v2f v = {(float)acc[nt][2 * h], (float)acc[nt][2 * h + 1]};
+                    if constexpr (BIAS) v = v + nb[nt][h];
+                    u2[h] = v * ninv[nt][h];
+                    u2[h] = u2[h] + nshift[nt][h];
                 }
                 int cb[4];
                 if (binary) {
                     asm volatile("; binary_tanh codes");
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) cb[i] = u4[i] > 0x1p-24f ? kMagicBits + 1 : kMagicBits - 1;
+                    for (int i = 0; i < 4; ++i) cb[i] = u2[i >> 1][i & 1] > 0x1p-24f ? kMagicBits + 1 : kMagicBits - 1;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int bits = __float_as_int(__fadd_rn(u4[i], kMagic));
-                        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cb[i]) : "v"(bits), "v"(code_lo), "v"(code_hi));
+                    for (int h = 0; h < 2; ++h) {
+                        const v2f t = u2[h] + magic2;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int bits = __float_as_int(t[j]);
+                            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cb[2 * h + j]) : "v"(bits), "v"(code_lo), "v"(code_hi));
+                        }
                     }
                 }
                 uint32_t P = ((uint32_t)cb[1] << 4) | (uint32_t)cb[0];

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time ONE packed 3x3 (or 1x1) int4/int8 conv layer with a fused BN + quantized_tanh epilogue, as the fused engines
 launch it.  Usage:  tools/bench_conv.py N H W CIN COUT [k=3] [stride=1] [bits=4] [res=0|1] [opt=key:val,...] [out=i4|f32]
+[store=4|8 (packed storage of the codes; 8 = `bits`-bit codes kept in bytes)] [pool=1|2]
 Prints one JSON line per call: kernel tag, us, pixels/us, fraction of the 8 TB/s HBM roof on in + out (+ shortcut)."""
 import importlib
 import json
@@ -25,7 +26,8 @@ def main():
         key, val = item.split(":")
         abi.set_option(key, int(val))
     rng = np.random.default_rng(0)
-    store = abi.store_for_bits(bits)
+    store = int(kw["store"]) if "store" in kw else abi.store_for_bits(bits)
+    pool = int(kw.get("pool", 1))
     op = {"op": "conv", "kind": "quantized", "nb": bits, "kernel": rng.uniform(-1, 1, (k, k, cin, cout)).astype(np.float32),
           "bias": None, "strides": (stride, stride), "padding": "same"}
     w = engine._prepack(op, store, torch.device("cuda"), stride=stride, same_pad=True)
@@ -43,7 +45,7 @@ def main():
 
     def launch():
         return abi.conv2d(w, xp, store, bits, N, H, W, inv if out == "i4" else None, shift if out == "i4" else None,
-                          fn, bits if out == "i4" else 0, 1, out_store, **rkw)[0]
+                          fn, bits if out == "i4" else 0, pool, out_store, **rkw)[0]
 
     for _ in range(5):
         launch()
@@ -59,10 +61,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 20)
-    in_b = N * H * W * cin * bits / 8
-    out_b = N * Ho * Wo * cout * (bits / 8 if out == "i4" else 4)
+    sb = store if store in (4, 8) else bits
+    in_b = N * H * W * cin * sb / 8
+    out_b = N * (Ho // pool) * (Wo // pool) * cout * (sb / 8 if out == "i4" else 4)
     tot = in_b + out_b * (2 if res else 1)
-    print(json.dumps({"kernel": abi.last_kernel(), "shape": [N, H, W, cin, cout, k, stride], "res": res, "out": out,
+    print(json.dumps({"kernel": abi.last_kernel(), "shape": [N, H, W, cin, cout, k, stride], "res": res, "out": out, "store": store, "pool": pool,
                       "opt": kw.get("opt", ""), "us": round(best * 1e3, 2),
                       "Mpix_per_s": round(N * Ho * Wo / best / 1e3, 1),
                       "TMACps": round(N * Ho * Wo * k * k * cin * cout / best / 1e9, 1),

@@ -24,10 +24,11 @@ model = engine.FusedModel(spec, first_layer="exact" if first == "u8" else first)
 a = nets.synthetic_images_u8(cf, N, 3)
 x1 = torch.as_tensor(a if first == "u8" else (a.astype(np.float32) / np.float32(255))).cuda()
 xb = x1.repeat(NB, 1, 1, 1)
-pipe = engine.Pipelined(model, lanes=2, batch_size=N)
+LANES = int(os.environ.get("LANES", "2"))
+pipe = engine.Pipelined(model, lanes=LANES, batch_size=N)
 pipe(xb[:2 * N])
 torch.cuda.synchronize()
-res = {"first": first, "batches": NB}
+res = {"first": first, "batches": NB, "lanes": LANES}
 for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -42,7 +43,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(NB):
-        ln = lanes[i % 2]
+        ln = lanes[i % LANES]
         with torch.cuda.stream(ln["stream"]):
             ln["graph"].replay()
     t1 = time.perf_counter()

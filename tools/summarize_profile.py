@@ -104,11 +104,14 @@ def traffic_json(root, out_path, bench_json=None):
                 res.setdefault(k, {})[key] = sum(v) / len(v)
     for f in find(os.path.join(root, "trace"), "kernel_trace.csv"):
         dur = defaultdict(list)
+        grids = defaultdict(set)
         for r in csv.DictReader(open(f)):
             dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            grids[short(r["Kernel_Name"])].add(r.get("Grid_Size_X", "?"))
         for k, v in dur.items():
             res.setdefault(k, {})["avg_us"] = sum(v) / len(v) / 1e3
             res[k]["calls"] = len(v)
+            res[k]["grids"] = len(grids[k])     # > 1: one template instance served several layers, averages mix them
     tags = []
     if bench_json and os.path.exists(bench_json):
         for line in open(bench_json):
@@ -124,7 +127,7 @@ def traffic_json(root, out_path, bench_json=None):
     by_tag = {}
     for tag in dict.fromkeys(tags):
         names = rocprof_names_for(tag, list(res))
-        if len(names) == 1:
+        if len(names) == 1 and res[names[0]].get("grids", 1) == 1:     # a per-launch figure only where it is one layer's
             by_tag[tag] = dict(res[names[0]], rocprof_kernel=names[0])
     json.dump({"by_tag": by_tag, "by_kernel": res}, open(out_path, "w"), indent=1, sort_keys=True)
 
