@@ -80,6 +80,7 @@ typedef struct qnn_weights qnn_weights_t;   /* opaque prepacked layer weights */
 /*
  * Epilogue fused behind the contraction.  Steps, in the reference's op order:
  *   v = acc * 2^-(wshift+xshift)             conv / matmul result (exact)
+ *   v = (v - trick_c*v) * trick_s             only if trick_s != 0 ("faithful" output side, see below)
  *   v = v + bias[c]                           K.bias_add   (if the layer has bias)
  *   v = v*bn_inv[c] + bn_shift[c]             inference BatchNormalization, two
  *                                             roundings (vgg.py:16, resnet.py:61)
@@ -91,6 +92,17 @@ typedef struct qnn_weights qnn_weights_t;   /* opaque prepacked layer weights */
  *   store as out_store (F32 value, or packed code)
  * bn_inv / bn_shift are device pointers to per-channel float32 constants formed
  * by the host exactly as tf.nn.batch_normalization forms them; NULL = no BN.
+ *
+ * trick_c / trick_s -- the reference wraps its convolutions in an lr-multiplier "identity trick"
+ * (layers/binary_layers.py:163-165,175-176, quantized_layers.py:167-169,179-180):
+ *     outputs = (o - (1. - 1./klm) * stop_gradient(o)) * klm
+ * which is the identity in real numbers and a float32 no-op up to rounding noise (~klm * ulp(o)).  By default
+ * (trick_s = 0, "exact" mode) it is evaluated as the identity.  A caller who wants the reference's OUTPUT-side noise
+ * reproduced bit for bit -- it moves 8-bit activation codes sitting on rounding ties -- passes the two float32 constants
+ * the reference forms, trick_c = 1 - 1/klm and trick_s = klm; the three float32 operations then run on the exact conv
+ * result before the bias.  Only the VALU kernel families (and the generic kernel) implement it: a launch with
+ * trick_s != 0 bypasses the matrix-pipe kernels.  The INPUT-side trick (163-165) perturbs grid-valued inputs by at most
+ * one ulp and would make the contraction a float32 problem; it stays the identity.
  */
 typedef struct qnn_epilogue {
     const float* bn_inv;     /* [cout] or NULL                                  */
@@ -104,6 +116,8 @@ typedef struct qnn_epilogue {
     int32_t res_store;       /* QNN_STORE_F32 | _BIN | _I4 | _I8                   */
     int32_t res_bits;        /* packed: value = code / 2^(res_bits-1) (BIN: +-1)    */
     float post_scale;        /* multiplier after the add (0.5 in resnet.py:128; 1 = none) */
+    float trick_c;           /* output-side identity trick: 1 - 1/klm (ignored when trick_s == 0) */
+    float trick_s;           /* klm, or 0 = the trick is the identity (default)                    */
 } qnn_epilogue_t;
 
 /* ---- library ------------------------------------------------------------ */

@@ -25,6 +25,8 @@ Two conv modes (hard part 2):
   * ``exact``    - the lr-multiplier "identity trick" of the reference
                    (binary_layers.py:163-165,175-176) is treated as the identity,
                    so low-bit layers produce exactly-representable values.
+  * ``faithful_out`` - only the OUTPUT side of the trick is replayed (the product's optional
+                   trick_c / trick_s epilogue, include/qnn_abi.h); the contraction stays exact.
   * ``faithful`` - the trick is replayed in float32 with the constants the
                    reference forms (numpy-1.x or NEP-50 scalar promotion).
 The contraction itself is accumulated in float64 and rounded once to float32:
@@ -376,6 +378,11 @@ def _conv_call(x, qkernel, bias, klm, strides, padding, mode, promotion):
         xin = _trick(x, c_in, s_in)
         o = conv2d(xin, qkernel, strides, padding)
         out = _trick(o, c_out, s_out)
+    elif mode == "faithful_out":
+        # the product's optional middle ground (include/qnn_abi.h, trick_c / trick_s): exact contraction, then the
+        # reference's OUTPUT-side trick (binary_layers.py:175-176) in float32; the input side stays the identity
+        c_in, s_in, c_out, s_out = trick_constants(klm, promotion)
+        out = _trick(_conv(x, qkernel, strides, padding), c_out, s_out)
     else:
         raise ValueError(mode)
     if bias is not None:
@@ -416,7 +423,7 @@ def quantized_dense_call(x, kernel, bias=None, nb=16):
 def _ternary_kernel(kernel, H, mode):
     """ternarize(W, H) (ternary_ops.py:33-41).  'faithful' replays W + (Wt - W) in float32,
     which leaves some weights one ulp off {-H, 0, H}; 'exact' takes it as Wt."""
-    return _ternarize(kernel, H) if mode == "exact" else ternarize(kernel, H)
+    return _ternarize(kernel, H) if mode in ("exact", "faithful_out") else ternarize(kernel, H)
 
 
 def ternary_conv2d_call(x, kernel, bias=None, H=1.0, strides=(1, 1), padding="same", mode="exact"):

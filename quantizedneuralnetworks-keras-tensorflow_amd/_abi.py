@@ -32,7 +32,7 @@ class Epilogue(ctypes.Structure):
                 ("fn", ctypes.c_int32), ("act_bits", ctypes.c_int32),
                 ("pool", ctypes.c_int32), ("out_store", ctypes.c_int32),
                 ("res", ctypes.c_void_p), ("res_store", ctypes.c_int32), ("res_bits", ctypes.c_int32),
-                ("post_scale", ctypes.c_float)]
+                ("post_scale", ctypes.c_float), ("trick_c", ctypes.c_float), ("trick_s", ctypes.c_float)]
 
 
 class QnnError(RuntimeError):
@@ -261,13 +261,31 @@ def out_hw(size, k, stride, same_pad):
 
 
 def make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res=None, res_store=STORE_F32,
-                  res_bits=0, post_scale=1.0):
+                  res_bits=0, post_scale=1.0, trick=None):
+    """trick: None (the reference's lr-multiplier identity trick is the identity) or the (c, s) float32 pair of its
+    OUTPUT side, `faithful_trick(klm, promotion)`."""
+    tc, ts = (float(trick[0]), float(trick[1])) if trick is not None else (0.0, 0.0)
     return Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store,
-                    ptr(res).value, res_store, res_bits, float(post_scale))
+                    ptr(res).value, res_store, res_bits, float(post_scale), tc, ts)
+
+
+def faithful_trick(klm, promotion="nep50"):
+    """The two float32 constants of `(o - (1. - 1./klm) * o) * klm` (binary_layers.py:175-176) as the reference forms
+    them: `promotion` = "nep50" (numpy >= 2: everything stays float32) or "legacy" (numpy < 2: `1. - 1./np.float32`
+    is float64, cast to float32 when it meets the tensor)."""
+    import numpy as np
+    k = np.float32(klm)
+    if promotion == "legacy":
+        c = np.float32(1.0 - 1.0 / float(k))
+    elif promotion == "nep50":
+        c = np.float32(1.0) - np.float32(1.0) / k
+    else:
+        raise ValueError(promotion)
+    return float(np.float32(c)), float(k)
 
 
 def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
-           pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0, out=None):
+           pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0, out=None, trick=None):
     """Run qnn_conv2d_forward; x is a float32 NHWC tensor, a uint8 NHWC tensor or an int32 packed tensor.
     Returns (y, Hp, Wp): y float32 (N,Hp,Wp,cout) or int32 (N*Hp*Wp, words); `out` = a tensor of that shape to write
     into instead of a fresh one."""
@@ -284,7 +302,7 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
         if tuple(out.shape) != shape or out.dtype != dt or not out.is_contiguous() or out.device != x.device:
             raise QnnError("conv2d: `out` must be a contiguous %s tensor of shape %s on %s" % (dt, shape, x.device))
         y = out
-    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale)
+    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale, trick)
     check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
                                     ptr(y), stream_ptr()), "qnn_conv2d_forward")
     return y, Ho, Wo
@@ -295,9 +313,10 @@ class BoundStep:
     of Python.  `x` / `y` are the step's static input / output tensors; either pointer can be overridden per call (a
     pipeline's first step reads the caller's batch in place, its last step writes into the caller's result)."""
 
-    def __init__(self, kind, w, x_store, x_bits, N, H, W, bn_inv, bn_shift, fn, act_bits, pool, out_store, x, y):
+    def __init__(self, kind, w, x_store, x_bits, N, H, W, bn_inv, bn_shift, fn, act_bits, pool, out_store, x, y,
+                 trick=None):
         self._keep = (w, bn_inv, bn_shift, x, y)
-        self._epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store)
+        self._epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, trick=trick)
         self._x = x.data_ptr() if x is not None else 0
         self._y = y.data_ptr() if y is not None else 0
         lib = load()

@@ -127,6 +127,7 @@ struct EpiArgs {
     int res_cw;                // words (packed) or floats (f32) per residual pixel
     float res_scale;           // 2^-(res_bits-1)
     float post_scale;
+    float trick_c, trick_s;    // output-side identity trick of the reference ("faithful" mode); trick_s == 0: off
 };
 
 #ifdef __HIPCC__
@@ -220,6 +221,8 @@ __device__ __forceinline__ int qnn_dot(uint32_t a, uint32_t w, int acc) {
 
 // ---- epilogue: acc -> float value in the reference's op order -------------------
 __device__ __forceinline__ float qnn_epi_value(float v, int c, const EpiArgs& e) {
+    // binary_layers.py:175-176: (o - (1 - 1/klm) * o) * klm, three float32 roundings ("faithful" mode only)
+    if (e.trick_s != 0.0f) v = __fmul_rn(__fsub_rn(v, __fmul_rn(e.trick_c, v)), e.trick_s);
     if (e.bias) v = __fadd_rn(v, e.bias[c]);
     if (e.bn_inv) v = __fadd_rn(__fmul_rn(v, e.bn_inv[c]), e.bn_shift[c]);
     return v;

@@ -1086,6 +1086,10 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
     e->res_cw = 0;
     e->res_scale = 1.0f;
     e->post_scale = epi->res ? epi->post_scale : 1.0f;
+    e->trick_c = epi->trick_s != 0.0f ? epi->trick_c : 0.0f;
+    e->trick_s = epi->trick_s;
+    QNN_REQUIRE(epi->trick_s == 0.0f || (epi->trick_s > 0.0f && epi->trick_s < 1.0e6f), QNN_EINVAL,
+                "epilogue: trick_s=%g (the layer's kernel_lr_multiplier, or 0)", (double)epi->trick_s);
     if (epi->res) {
         QNN_REQUIRE(epi->pool == 1, QNN_EINVAL, "epilogue: a residual input cannot be combined with pooling");
         switch (epi->res_store) {
@@ -1142,6 +1146,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
                     w->wkind, w->wbits);
         QNN_REQUIRE(w->H == 1.0f || w->wkind == QNN_W_QUANT, QNN_EUNSUPPORTED, "conv_forward: QNN_STORE_U8 input needs H = 1");
         QNN_REQUIRE(!epi->res, QNN_EUNSUPPORTED, "conv_forward: no residual input behind a QNN_STORE_U8 layer");
+        QNN_REQUIRE(epi->trick_s == 0.0f, QNN_EUNSUPPORTED, "conv_forward: no faithful trick on the QNN_STORE_U8 entry");
         QNN_REQUIRE((double)w->kh * w->kw * w->cin * 255.0 * (double)(1 << w->wshift) < 16777216.0, QNN_EUNSUPPORTED,
                     "conv_forward: QNN_STORE_U8 sums of this layer exceed 2^24");
     } else {
@@ -1190,7 +1195,10 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     char name[64];
     // the pixel-stationary kernel needs whole pool windows (even Ho/Wo are not
     // required: the remainder row/column is simply never produced)
-    const int pref = qnn_conv_impl_pref();
+    // "faithful" output-side trick: only the kernels whose epilogue is qnn_epi_value implement it
+    const bool trick = e.trick_s != 0.0f;
+    QNN_REQUIRE(!(trick && dense), QNN_EINVAL, "dense_forward: the reference's Dense layers have no identity trick");
+    const int pref = trick ? 1 : qnn_conv_impl_pref();
     bool launched = false;
     if (dense && !e.res && x_store != QNN_STORE_F32 && e.out_store == QNN_STORE_F32 && (w->kwords % 4) == 0) {
         int rc2 = x_store == QNN_STORE_BIN  ? launch_dense<QNN_STORE_BIN>(x, w, e, y, N, s)
@@ -1209,7 +1217,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
         launched = true;
         snprintf(name, sizeof(name), "dense_f32");
     }
-    if (!launched && !dense && x_store == QNN_STORE_I4 && try_launch_pw_f32(g, e, x, w, y, s) == 0) {
+    if (!launched && !dense && !trick && x_store == QNN_STORE_I4 && try_launch_pw_f32(g, e, x, w, y, s) == 0) {
         launched = true;
         snprintf(name, sizeof(name), "pw_i4_f32");
     }
@@ -1233,7 +1241,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     }
     if (!launched && pref != 1 && !dense)          // residual epilogues: only where the MFMA kernel has one
         launched = qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
-    if (!launched && x_store == QNN_STORE_BIN && !dense && !e.res)
+    if (!launched && x_store == QNN_STORE_BIN && !dense && !e.res && !trick)
         launched = try_launch_xnor_pk(g, e, x, w, y, s, name, sizeof(name)) == 0;
     if (!launched) launched = try_launch_ps(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
     if (launched) {
@@ -1424,7 +1432,7 @@ extern "C" int qnn_conv2d_forward_f32in(const qnn_weights_t* w, const float* x, 
                 QNN_EINVAL, "qnn_conv2d_forward_f32in: in_fn=%d", in_fn);
     const int x_bits = w->store == QNN_STORE_BIN ? 1 : in_bits;
     if (w->store == QNN_STORE_BIN && epi->out_store == QNN_STORE_F32 && epi->pool == 1 && N > 0 &&
-        !epi->res && qnn_conv_impl_pref() != 2) {
+        !epi->res && epi->trick_s == 0.0f && qnn_conv_impl_pref() != 2) {
         ConvGeom g;
         g.N = N; g.H = H; g.W = W;
         g.cin = w->cin; g.cout = w->cout; g.kh = w->kh; g.kw = w->kw; g.stride = w->stride;

@@ -113,9 +113,15 @@ class FusedModel:
 
     FIRST_LAYER_OPTION = {"exact": None, "fixed": "first_fixed", "image": "first_image"}
 
-    def __init__(self, spec, device="cuda", first_layer="exact"):
+    def __init__(self, spec, device="cuda", first_layer="exact", trick=None):
+        """trick: None = the reference's lr-multiplier identity trick is the identity ("exact" mode, the default), or
+        "nep50" / "legacy" = its OUTPUT side (binary_layers.py:175-176) is replayed in float32 behind every low-bit
+        conv with the constants the reference forms under that numpy promotion rule (qnn_abi.h, trick_c / trick_s):
+        reproduces the reference's rounding noise on 8-bit activation grids at the price of the VALU kernel family."""
         if first_layer not in self.FIRST_LAYER_OPTION:
             raise ValueError("first_layer must be 'exact', 'image' or 'fixed', got %r" % (first_layer,))
+        if trick not in (None, "nep50", "legacy"):
+            raise ValueError("trick must be None, 'nep50' or 'legacy', got %r" % (trick,))
         self.first_layer = first_layer
         self.device = torch.device(device)
         self.steps = []
@@ -161,9 +167,16 @@ class FusedModel:
                     if cout % _abi.per_word(out_store) != 0:
                         raise _abi.NotFusable("FusedModel: %d channels in front of Flatten do not fill whole "
                                               "packed words" % cout)
+            tk = None
+            if trick is not None and g["kind"] == "conv" and op["kind"] in ("binary", "quantized"):
+                kh_, kw_, ci_, co_ = op["kernel"].shape
+                klm = op.get("klm")
+                if klm is None:
+                    klm = np.float32(1.0 / np.sqrt(1.5 / (int(ci_ * kh_ * kw_) + int(co_ * kh_ * kw_))))
+                tk = _abi.faithful_trick(klm, trick)
             self.steps.append(dict(kind=g["kind"], w=w, x_store=x_store, x_bits=x_bits, inv=inv,
                                    shift=shift, fn=fn, act_bits=bits if fn == _abi.FN_QUANTIZED_TANH else 0,
-                                   pool=g["pool"], out_store=out_store, softmax=g.get("softmax", False)))
+                                   pool=g["pool"], out_store=out_store, softmax=g.get("softmax", False), trick=tk))
             x_store, x_bits = out_store, bits
 
     @staticmethod
@@ -219,7 +232,8 @@ class FusedModel:
             _abi.set_option(opt, 1)
         try:
             return _abi.conv2d(st["w"], cur, x_store, st["x_bits"], N, H, W, st["inv"],
-                               st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"], out=out)
+                               st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"], out=out,
+                               trick=None if u8 else st["trick"])
         finally:
             if opt:
                 _abi.set_option(opt, 0)
@@ -239,7 +253,8 @@ class FusedModel:
             x_store = _abi.STORE_U8 if (u8 and si == 0) else st["x_store"]
             bound.append(_abi.BoundStep(st["kind"], st["w"], x_store, st["x_bits"], N, H, W, st["inv"], st["shift"],
                                         st["fn"], st["act_bits"], st["pool"], st["out_store"],
-                                        None if si == 0 else cur, None if si == len(self.steps) - 1 else out))
+                                        None if si == 0 else cur, None if si == len(self.steps) - 1 else out,
+                                        trick=None if (u8 and si == 0) else st["trick"]))
             cur, H, W = out, H1, W1
         last = len(bound) - 1
 

@@ -249,3 +249,20 @@ def test_exact_vs_faithful_on_trained_checkpoints(code, wbits, abits, capsys):
     with capsys.disabled():
         print("\n[exact vs faithful, resnet3_full_%s] (differing codes, codes, argmax agreement, max|dp|): %s"
               % (code, report))
+
+
+@pytest.mark.parametrize("prom", ["nep50", "legacy"])
+def test_output_side_trick_alone_reproduces_the_8bit_network(prom):
+    """The product's optional `faithful_out` mode (exact contraction + the reference's OUTPUT-side identity trick in
+    float32, include/qnn_abi.h trick_c / trick_s): every one of the 166 one-LSB differences between exact integer
+    arithmetic and the reference's 8-bit network disappears, the logits are the reference's bit for bit."""
+    cf, spec, x, y_ref, trace = R.net("vgg_fullqnn88_w")
+    outs = _run(spec, x, "faithful_out", prom)
+    flips = total = 0
+    for i, j in R.align_trace(spec, trace):
+        cls, kind, val = trace[j]
+        if kind == "codes":
+            flips += int((outs[i].reshape(val.shape) != val).sum())
+            total += val.size
+    assert (flips, total) == (0, 348160)
+    np.testing.assert_array_equal(outs[-1], y_ref)
