@@ -29,6 +29,13 @@
  *                  2- and 3-bit activations are stored sign-extended in 4 bits.
  *   QNN_STORE_I8   signed 8-bit codes, 4 per uint32.
  *   Words per pixel = ceil(C / (32 / bits)).
+ *   QNN_STORE_T2   ternary codes {-1, 0, +1} as two bit planes, 2 bits / channel (layers/ternary_layers.py,
+ *                  ternary_ops.py): per 32 channels one MASK word (bit j = 1 <=> channel 32w+j is non-zero) followed
+ *                  by one SIGN word (bit j = 1 <=> +1; 0 where the mask is 0); 2 * ceil(C / 32) words per pixel.
+ *                  A ternary x ternary dot product is two popcounts: with m = mask_a & mask_w and d = sign_a ^ sign_w,
+ *                  sum = popc(m & ~d) - popc(m & d) = popc(m) - 2 popc(m & d).  A zero-padding tap is an all-zero
+ *                  mask: no border corrections.  Input-side storage (activations and weights); outputs are float32
+ *                  because ternary_tanh thresholds at a mean over the whole batch tensor (ternary_ops.py:23).
  *
  * Typed image input (first layer only):
  *   QNN_STORE_U8   the dataset's own bytes: NHWC, C unsigned bytes per pixel, no padding; value = code / 255,
@@ -58,6 +65,7 @@ extern "C" {
 /* storage kinds of activation / weight tensors */
 #define QNN_STORE_F32 0
 #define QNN_STORE_BIN 1
+#define QNN_STORE_T2  2   /* ternary sign / mask bit planes */
 #define QNN_STORE_I4  4
 #define QNN_STORE_I8  8
 #define QNN_STORE_U8  16  /* input only: unsigned image bytes, value = code / 255 */
@@ -190,7 +198,8 @@ int qnn_avgpool_packed_f32(const void* x, int store, int bits, int N, int H, int
  *   stride      : 1 or 2 (square); same_pad: 1 = 'same', 0 = 'valid'
  *   store       : packed kind to prepare for the integer path (QNN_STORE_BIN only
  *                 for QNN_W_BINARY; I4 needs wbits<=4; I8 needs wbits<=8; ternary
- *                 weights {-1,0,1} use I4 or I8), or
+ *                 weights {-1,0,1} use T2 -- against ternary activations -- or I4 / I8;
+ *                 binary weights may also be prepared as T2: +-1 with a full mask), or
  *                 QNN_STORE_F32 for "float32 inputs only" (first layer).
  */
 int qnn_prepack_weights(int wkind, int wbits, float H, const float* kernel,

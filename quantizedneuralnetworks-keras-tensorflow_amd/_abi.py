@@ -13,7 +13,7 @@ import torch
 from . import _build
 
 QNN_OK = 0
-STORE_F32, STORE_BIN, STORE_I4, STORE_I8, STORE_U8 = 0, 1, 4, 8, 16
+STORE_F32, STORE_BIN, STORE_T2, STORE_I4, STORE_I8, STORE_U8 = 0, 1, 2, 4, 8, 16
 W_FLOAT, W_BINARY, W_QUANT, W_TERNARY = 0, 1, 2, 3
 FN_NONE, FN_BINARY_TANH, FN_QUANTIZED_TANH, FN_TERNARY_TANH, FN_GRID = 0, 1, 2, 3, 4
 
@@ -166,10 +166,13 @@ def ptr(t):
 
 
 def per_word(store):
-    return {STORE_BIN: 32, STORE_I4: 8, STORE_I8: 4}[store]
+    """Channels a whole packed word (T2: word pair) covers."""
+    return {STORE_BIN: 32, STORE_T2: 32, STORE_I4: 8, STORE_I8: 4}[store]
 
 
 def words(store, channels):
+    if store == STORE_T2:                      # (mask, sign) word pairs per 32 channels
+        return 2 * ((channels + 31) // 32)
     pw = per_word(store)
     return (channels + pw - 1) // pw
 

@@ -140,6 +140,7 @@ QNN_HD static inline int qnn_per_word(int store) {
     return store == QNN_STORE_BIN ? 32 : store == QNN_STORE_I4 ? 8 : store == QNN_STORE_I8 ? 4 : 1;
 }
 QNN_HD static inline int qnn_words(int store, int channels) {
+    if (store == QNN_STORE_T2) return 2 * ((channels + 31) / 32);     // (mask, sign) word pairs
     int pw = qnn_per_word(store);
     return (channels + pw - 1) / pw;
 }
@@ -210,6 +211,12 @@ __device__ __forceinline__ int qnn_dot_i4(uint32_t a, uint32_t w, int acc) {
 // 4 x (int8 * int8) + acc  -> v_dot4_i32_i8
 __device__ __forceinline__ int qnn_dot_i8(uint32_t a, uint32_t w, int acc) {
     return __builtin_amdgcn_sdot4((int)a, (int)w, acc, false);
+}
+
+// ternary x ternary on (mask, sign) word pairs: popc(m) - 2 popc(m & (sa ^ sw)),  m = ma & mw
+__device__ __forceinline__ int qnn_dot_t2(uint32_t ma, uint32_t sa, uint32_t mw, uint32_t sw, int acc) {
+    const uint32_t m = ma & mw;
+    return acc + __popc(m) - 2 * __popc(m & (sa ^ sw));
 }
 
 template <int STORE>

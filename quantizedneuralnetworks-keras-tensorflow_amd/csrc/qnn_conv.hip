@@ -105,6 +105,25 @@ __global__ __launch_bounds__(kBlock) void k_prepack_codes(const float* __restric
     }
 }
 
+// ternary (or binary) weight values -> (mask, sign) word pairs per 32 input channels, QNN_STORE_T2
+__global__ __launch_bounds__(kBlock) void k_prepack_t2(const float* __restrict__ wq, uint32_t* __restrict__ packed,
+                                                       int taps, int cin, int cout, int pairs) {
+    const int total = cout * taps * pairs;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const int w = i % pairs;
+        const int ct = i / pairs;   // c*taps + t
+        const float* src = wq + (size_t)ct * cin + w * 32;
+        const int left = cin - w * 32;
+        uint32_t mask = 0, sign = 0;
+        for (int j = 0; j < 32 && j < left; ++j) {
+            mask |= (src[j] != 0.0f ? 1u : 0u) << j;
+            sign |= (src[j] > 0.0f ? 1u : 0u) << j;
+        }
+        packed[2 * i] = mask;
+        packed[2 * i + 1] = sign;
+    }
+}
+
 // BIN zero-padding corrections.  Out-of-image taps are fed as all-zero words
 // (= every channel -1), so their spurious contribution sum_c (-1)*w_c must be
 // removed: corr[rmask*8+cmask][c] = sum over taps (dy,dx) with dy in rmask or dx in
@@ -196,6 +215,8 @@ __device__ float conv_point(const ConvGeom& g, int x_store, const void* __restri
                 int p = 0;
                 for (int j = 0; j < g.cw; ++j) p += __popc(a[j] ^ w[j]);
                 acc += g.cin - 2 * p;   // pad bits are 0 in both operands
+            } else if (x_store == QNN_STORE_T2) {
+                for (int j = 0; j < g.cw; j += 2) acc = qnn_dot_t2(a[j], a[j + 1], w[j], w[j + 1], acc);
             } else if (x_store == QNN_STORE_I4) {
                 for (int j = 0; j < g.cw; ++j) acc = qnn_dot_i4(a[j], w[j], acc);
             } else {
@@ -510,8 +531,13 @@ __global__ __launch_bounds__(kBlock) void k_conv_ps(ConvGeom g, EpiArgs e,
                 v = acc;
             } else {
                 int acc = 0;
+                if constexpr (XS == QNN_STORE_T2) {
 #pragma unroll
-                for (int k = 0; k < KWORDS; ++k) acc = qnn_dot<XS>(a[k], w[k], acc);
+                    for (int k = 0; k < KWORDS; k += 2) acc = qnn_dot_t2(a[k], a[k + 1], w[k], w[k + 1], acc);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KWORDS; ++k) acc = qnn_dot<XS>(a[k], w[k], acc);
+                }
                 if constexpr (XS == QNN_STORE_BIN) {
                     acc = ktot - 2 * acc;
                     if (corr) acc += corr[cls * g.cout + c];
@@ -564,12 +590,21 @@ __global__ __launch_bounds__(kBlock) void k_dense_packed(const uint32_t* __restr
     for (; k + 4 <= kwords; k += 4) {
         const uint4 a = *reinterpret_cast<const uint4*>(xr + k);
         const uint4 w = *reinterpret_cast<const uint4*>(wr + k);
-        acc = qnn_dot<XS>(a.x, w.x, acc);
-        acc = qnn_dot<XS>(a.y, w.y, acc);
-        acc = qnn_dot<XS>(a.z, w.z, acc);
-        acc = qnn_dot<XS>(a.w, w.w, acc);
+        if constexpr (XS == QNN_STORE_T2) {          // two (mask, sign) pairs
+            acc = qnn_dot_t2(a.x, a.y, w.x, w.y, acc);
+            acc = qnn_dot_t2(a.z, a.w, w.z, w.w, acc);
+        } else {
+            acc = qnn_dot<XS>(a.x, w.x, acc);
+            acc = qnn_dot<XS>(a.y, w.y, acc);
+            acc = qnn_dot<XS>(a.z, w.z, acc);
+            acc = qnn_dot<XS>(a.w, w.w, acc);
+        }
     }
-    for (; k < kwords; ++k) acc = qnn_dot<XS>(xr[k], wr[k], acc);
+    if constexpr (XS == QNN_STORE_T2) {
+        for (; k < kwords; k += 2) acc = qnn_dot_t2(xr[k], xr[k + 1], wr[k], wr[k + 1], acc);
+    } else {
+        for (; k < kwords; ++k) acc = qnn_dot<XS>(xr[k], wr[k], acc);
+    }
     if constexpr (XS == QNN_STORE_BIN) acc = cin - 2 * acc;   // pad bits are 0 in both operands
     float v = __fmul_rn((float)acc, e.scale);
     v = qnn_epi_value(v, u, e);
@@ -597,10 +632,15 @@ __global__ __launch_bounds__(kBlock) void k_dense_packed_split(const uint32_t* _
     for (int k = kp * 4; k + 4 <= kwords; k += 4 * KP) {
         const uint4 a = *reinterpret_cast<const uint4*>(xr + k);
         const uint4 w = *reinterpret_cast<const uint4*>(wr + k);
-        acc = qnn_dot<XS>(a.x, w.x, acc);
-        acc = qnn_dot<XS>(a.y, w.y, acc);
-        acc = qnn_dot<XS>(a.z, w.z, acc);
-        acc = qnn_dot<XS>(a.w, w.w, acc);
+        if constexpr (XS == QNN_STORE_T2) {
+            acc = qnn_dot_t2(a.x, a.y, w.x, w.y, acc);
+            acc = qnn_dot_t2(a.z, a.w, w.z, w.w, acc);
+        } else {
+            acc = qnn_dot<XS>(a.x, w.x, acc);
+            acc = qnn_dot<XS>(a.y, w.y, acc);
+            acc = qnn_dot<XS>(a.z, w.z, acc);
+            acc = qnn_dot<XS>(a.w, w.w, acc);
+        }
     }
 #pragma unroll
     for (int d = 1; d < KP; d <<= 1) acc += __shfl_xor(acc, d);     // every lane of the group takes part
@@ -1033,7 +1073,7 @@ int try_launch_ps(const ConvGeom& g, const EpiArgs& e, int x_store, const void* 
     const int32_t* corr = (x_store == QNN_STORE_BIN && w->same_pad && g.kh == 3) ? w->d_corr : nullptr;
     const int cw = x_store == QNN_STORE_F32 ? g.cin : g.cw;
     const char* xs = x_store == QNN_STORE_F32 ? "f32" : x_store == QNN_STORE_BIN ? "bin"
-                     : x_store == QNN_STORE_I4 ? "i4" : "i8";
+                     : x_store == QNN_STORE_T2 ? "t2" : x_store == QNN_STORE_I4 ? "i4" : "i8";
     snprintf(name, name_len, "ps_%s_cw%d_k%d", xs, cw, g.kh);
 #define PS_CASE(XS, CW, K)                                                     \
     if (x_store == XS && cw == CW && g.kh == K)                                \
@@ -1046,6 +1086,11 @@ int try_launch_ps(const ConvGeom& g, const EpiArgs& e, int x_store, const void* 
     PS_CASE(QNN_STORE_BIN, 8, 3)
     PS_CASE(QNN_STORE_BIN, 1, 1)
     PS_CASE(QNN_STORE_BIN, 2, 1)
+    PS_CASE(QNN_STORE_T2, 2, 3)       // 2 words per 32 channels: Cin <= 32 / 64 / 128
+    PS_CASE(QNN_STORE_T2, 4, 3)
+    PS_CASE(QNN_STORE_T2, 8, 3)
+    PS_CASE(QNN_STORE_T2, 2, 1)
+    PS_CASE(QNN_STORE_T2, 4, 1)
     PS_CASE(QNN_STORE_I4, 2, 3)
     PS_CASE(QNN_STORE_I4, 4, 3)
     PS_CASE(QNN_STORE_I4, 8, 3)
@@ -1153,7 +1198,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
         QNN_REQUIRE(x_store == w->store, QNN_EINVAL,
                     "conv_forward: x_store=%d but the weights were prepacked for store=%d",
                     x_store, w->store);
-        if (x_store != QNN_STORE_BIN) {
+        if (x_store != QNN_STORE_BIN && x_store != QNN_STORE_T2) {      // BIN / T2: value = code
             QNN_REQUIRE(x_bits >= 1 && x_bits <= x_store, QNN_EINVAL,
                         "conv_forward: x_bits=%d does not fit %d-bit storage", x_bits, x_store);
             xshift = x_bits - 1;
@@ -1202,11 +1247,13 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     bool launched = false;
     if (dense && !e.res && x_store != QNN_STORE_F32 && e.out_store == QNN_STORE_F32 && (w->kwords % 4) == 0) {
         int rc2 = x_store == QNN_STORE_BIN  ? launch_dense<QNN_STORE_BIN>(x, w, e, y, N, s)
+                  : x_store == QNN_STORE_T2 ? launch_dense<QNN_STORE_T2>(x, w, e, y, N, s)
                   : x_store == QNN_STORE_I4 ? launch_dense<QNN_STORE_I4>(x, w, e, y, N, s)
                                             : launch_dense<QNN_STORE_I8>(x, w, e, y, N, s);
         if (rc2 == 0) {
             launched = true;
-            snprintf(name, sizeof(name), "dense_%s", x_store == QNN_STORE_BIN ? "bin" : x_store == QNN_STORE_I4 ? "i4" : "i8");
+            snprintf(name, sizeof(name), "dense_%s", x_store == QNN_STORE_BIN ? "bin" : x_store == QNN_STORE_T2 ? "t2"
+                                                     : x_store == QNN_STORE_I4 ? "i4" : "i8");
         }
     }
     if (!launched && dense && !e.res && x_store == QNN_STORE_F32 && e.out_store == QNN_STORE_F32 && w->d_wq &&
@@ -1295,6 +1342,10 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
                         QNN_EINVAL, "qnn_prepack_weights: wkind=%d wbits=%d does not fit %d-bit storage",
                         wkind, wbits, store);
             break;
+        case QNN_STORE_T2:
+            QNN_REQUIRE((wkind == QNN_W_BINARY || wkind == QNN_W_TERNARY) && H == 1.0f, QNN_EINVAL,
+                        "qnn_prepack_weights: sign / mask storage needs ternary (or binary) weights with H=1");
+            break;
         default:
             qnn_set_error("qnn_prepack_weights: store=%d", store);
             return QNN_EINVAL;
@@ -1344,7 +1395,10 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
         PREPACK_HIP(hipMalloc(&w->d_packed, nw * sizeof(uint32_t)));
         grid = (int)((nw + kBlock - 1) / kBlock);
         if (grid > 4096) grid = 4096;
-        if (store == QNN_STORE_BIN)
+        if (store == QNN_STORE_T2)
+            hipLaunchKernelGGL(k_prepack_t2, dim3(grid), dim3(kBlock), 0, s, w->d_wq, w->d_packed, taps, cin, cout,
+                               w->cw / 2);
+        else if (store == QNN_STORE_BIN)
             hipLaunchKernelGGL(k_prepack_codes<QNN_STORE_BIN>, dim3(grid), dim3(kBlock), 0, s, w->d_wq,
                                w->d_packed, taps, cin, cout, w->cw, m);
         else if (store == QNN_STORE_I4)

@@ -163,6 +163,38 @@ __global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ x,
     }
 }
 
+// ternary grid values {-1, 0, +1} -> (mask, sign) word pairs; one thread per pair (32 channels of one pixel)
+__global__ __launch_bounds__(kBlock) void k_pack_t2(const float* __restrict__ x, uint32_t* __restrict__ y,
+                                                    size_t pixels, int channels, int pairs) {
+    const size_t total = pixels * (size_t)pairs;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const size_t p = i / pairs;
+        const int w = (int)(i - p * pairs);
+        const float* src = x + p * (size_t)channels + (size_t)w * 32;
+        const int left = channels - w * 32;
+        uint32_t mask = 0, sign = 0;
+        for (int j = 0; j < 32 && j < left; ++j) {
+            const float v = src[j];
+            mask |= (v != 0.0f ? 1u : 0u) << j;
+            sign |= (v > 0.0f ? 1u : 0u) << j;
+        }
+        y[2 * i] = mask;
+        y[2 * i + 1] = sign;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_t2(const uint32_t* __restrict__ x, float* __restrict__ y,
+                                                      size_t pixels, int channels, int pairs) {
+    const size_t n = pixels * (size_t)channels;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const size_t p = i / channels;
+        const int c = (int)(i - p * channels);
+        const uint32_t mask = x[(p * pairs + c / 32) * 2], sign = x[(p * pairs + c / 32) * 2 + 1];
+        y[i] = ((mask >> (c & 31)) & 1u) ? (((sign >> (c & 31)) & 1u) ? 1.0f : -1.0f) : 0.0f;
+    }
+}
+
 // BIN pack, channels % 32 == 0: the packed bit index equals the flat element index, so
 // lane = element: one coalesced dword load per lane, one compare, and the wave's 64-bit
 // lane mask IS two packed words (v_cmp writes it straight into an SGPR pair).  Eight
@@ -338,7 +370,7 @@ extern "C" int qnn_ternary_tanh_f32(const float* x, float* y, size_t n, void* wo
 
 extern "C" size_t qnn_packed_bytes(int store, size_t pixels, int channels) {
     if (store == QNN_STORE_F32) return pixels * (size_t)channels * 4;
-    if (store != QNN_STORE_BIN && store != QNN_STORE_I4 && store != QNN_STORE_I8) return 0;
+    if (store != QNN_STORE_BIN && store != QNN_STORE_I4 && store != QNN_STORE_I8 && store != QNN_STORE_T2) return 0;
     return pixels * (size_t)qnn_words(store, channels) * 4;
 }
 
@@ -361,6 +393,14 @@ extern "C" int qnn_pack_f32(const float* x, void* y, size_t pixels, int channels
                         "qnn_pack_f32: nb=%d does not fit %d-bit storage", nb, store);
             m = (float)(1u << (nb - 1));
         }
+    } else if (store == QNN_STORE_T2) {
+        QNN_REQUIRE(fn == QNN_FN_GRID, QNN_EINVAL,
+                    "qnn_pack_f32: QNN_STORE_T2 packs values that are already {-1, 0, +1} (fn = QNN_FN_GRID): "
+                    "ternary_tanh needs the batch-wide mean first (qnn_ternary_tanh_f32)");
+        hipLaunchKernelGGL(k_pack_t2, dim3(grid_for(pixels * (size_t)(cw / 2))), dim3(kBlock), 0, (hipStream_t)stream, x,
+                           (uint32_t*)y, pixels, channels, cw / 2);
+        QNN_HIP(hipGetLastError());
+        return QNN_OK;
     } else {
         qnn_set_error("qnn_pack_f32: store=%d is not a packed kind", store);
         return QNN_EINVAL;
@@ -392,6 +432,11 @@ extern "C" int qnn_unpack_f32(const void* x, float* y, size_t pixels, int channe
     hipStream_t s = (hipStream_t)stream;
     const int g = grid_for(pixels * (size_t)channels);
     float inv_m = 1.0f;
+    if (store == QNN_STORE_T2) {
+        hipLaunchKernelGGL(k_unpack_t2, dim3(g), dim3(kBlock), 0, s, (const uint32_t*)x, y, pixels, channels, cw / 2);
+        QNN_HIP(hipGetLastError());
+        return QNN_OK;
+    }
     if (store != QNN_STORE_BIN) {
         QNN_REQUIRE(nb >= 1 && nb <= store, QNN_EINVAL, "qnn_unpack_f32: nb=%d vs store=%d", nb, store);
         inv_m = 1.0f / (float)(1u << (nb - 1));

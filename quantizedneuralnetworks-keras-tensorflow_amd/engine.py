@@ -26,6 +26,11 @@ from .layers import binary_ops, quantized_ops, ternary_ops
 
 F32 = np.float32
 
+# Ternary activations x ternary weights (full-tnn networks, layers/ternary_layers.py) are stored as sign / mask bit
+# planes (QNN_STORE_T2, 2 bits per value) and contracted with two popcounts.  False = keep them as int4 codes (the
+# round-2 form; bit-identical results, tests run both).
+TERNARY_T2 = True
+
 
 def bn_constants(op):
     """tf.nn.batch_normalization constants in float32, formed on the host exactly
@@ -381,7 +386,9 @@ class GraphModel:
                 wstore = _wstore(op)
                 if isinstance(src, _Virtual) and wstore is not None:
                     bits = 1 if src.fn == _abi.FN_BINARY_TANH else src.nb
-                    if src.fn == _abi.FN_GRID:       # ternary codes {-1,0,1}: value = code, needs >= 4 bits
+                    if src.fn == _abi.FN_GRID and op["kind"] == "ternary" and TERNARY_T2:
+                        store = _abi.STORE_T2        # ternary x ternary: sign / mask planes, two popcounts
+                    elif src.fn == _abi.FN_GRID:     # ternary codes {-1,0,1}: value = code, needs >= 4 bits
                         store = max(_abi.STORE_I4, wstore if wstore != _abi.STORE_BIN else _abi.STORE_I4)
                     else:
                         store = _join_store(bits, wstore)
@@ -550,6 +557,18 @@ class ResidualFusedModel:
             return _abi.STORE_BIN
         return max([j for j in joins if j != _abi.STORE_BIN] + [_abi.STORE_I4])
 
+    def _users_through_pools(self, name):
+        """The ops that finally consume tensor `name`, looking through max-pools and flattens (both keep ternary
+        codes ternary)."""
+        out, todo = [], [name]
+        while todo:
+            for ci in self.cons.get(todo.pop(), []):
+                if self.spec[ci]["op"] in ("maxpool", "flatten"):
+                    todo.append(self.names[ci])
+                else:
+                    out.append(self.spec[ci])
+        return out
+
     # ---- evaluation --------------------------------------------------------------
     def forward(self, x):
         x = (_abi.require_cuda_u8(x, "ResidualFusedModel.forward")
@@ -568,6 +587,8 @@ class ResidualFusedModel:
             inv, shift = self._bn[bn_i] if bn_i is not None else (None, None)
             rkw = {}
             if res is not None:
+                if isinstance(res, _Packed) and res.store == _abi.STORE_T2:
+                    res = res.to_f32()           # the shortcut operand of the epilogue reads codes or float32, not bit planes
                 if isinstance(res, _Packed):
                     rkw = dict(res=res.t, res_store=res.store, res_bits=res.bits, post_scale=post_scale)
                 else:
@@ -675,6 +696,11 @@ class ResidualFusedModel:
                     elif fnn == "ternary_tanh":
                         out = ternary_ops.ternary_tanh(pre)
                         tstore = self._act_out_store(name, 4)      # codes {-1,0,1}: at least 4-bit storage
+                        users = self._users_through_pools(name)
+                        if TERNARY_T2 and any(u["op"] in ("conv", "dense") for u in users) and \
+                                all(u["op"] in ("add", "avgpool") or
+                                    (u["op"] in ("conv", "dense") and u["kind"] == "ternary") for u in users):
+                            tstore = _abi.STORE_T2                 # every contraction behind it has ternary weights
                         if tstore is not None:
                             out = _Packed(_abi.pack(out, out.shape[-1], _abi.FN_GRID, 1, tstore), tstore, 1, out.shape)
                     elif fnn == "leaky_relu":
@@ -714,11 +740,18 @@ class ResidualFusedModel:
             elif kind == "scale":
                 out = f32(self.srcs[i][0]) * F32(op["value"])
             elif kind == "maxpool":
-                t = f32(self.srcs[i][0]); s_ = op.get("size", 2)
+                src = ev(self.srcs[i][0])
+                t = src.to_f32() if isinstance(src, _Packed) else src
+                s_ = op.get("size", 2)
                 N, H, W, C = t.shape
                 out = t[:, :H // s_ * s_, :W // s_ * s_, :].reshape(N, H // s_, s_, W // s_, s_, C).amax(dim=(2, 4))
+                if isinstance(src, _Packed) and src.store == _abi.STORE_T2:
+                    # the maximum of ternary codes is a ternary code: stay on the bit planes for the next ternary layer
+                    out = _Packed(_abi.pack(out.contiguous(), C, _abi.FN_GRID, 1, src.store), src.store, src.bits, out.shape)
             elif kind == "avgpool":
                 src = ev(self.srcs[i][0]); s_ = op.get("size", 8)
+                if isinstance(src, _Packed) and src.store == _abi.STORE_T2:
+                    src = src.to_f32()
                 if isinstance(src, _Packed):     # window sums on the codes: no float32 copy of the activation
                     N, H, W, C = src.shape
                     out = _abi.avgpool_packed(src.t, src.store, src.bits, N, H, W, C, s_)

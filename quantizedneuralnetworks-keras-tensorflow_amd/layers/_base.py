@@ -73,6 +73,7 @@ class LowBitLayer:
         #   None                      any float32 values (generic float kernel)
         #   "binary"                  values are exactly +-1        -> XNOR/popcount path
         #   ("quantized", nb)         values are k/2**(nb-1)        -> packed int path
+        #   "ternary"                 values are exactly {-1,0,+1}  -> sign/mask planes (ternary layers) or int4
         #   ("binary_tanh",)          apply binary_tanh on load (fuses the Activation layer)
         #   ("quantized_tanh", nb)    apply quantized_tanh(nb) on load
         self.input_domain = kwargs.pop("input_domain", None)
@@ -150,6 +151,12 @@ class LowBitLayer:
             wbits_store = _abi.STORE_I4          # codes {-1, 0, 1}
         else:
             wbits_store = _abi.store_for_bits(self._wbits())
+        if self._wkind == _abi.W_TERNARY and (dom == "ternary" or dom == ("quantized", 1)):
+            from .. import engine
+            if engine.TERNARY_T2:          # values are {-1, 0, +1}: sign / mask planes against ternary weights
+                return _abi.STORE_T2, 1, _abi.FN_GRID, 1
+        if dom == "ternary":
+            dom = ("quantized", 1)
         if dom == "binary" or dom == ("binary_tanh",) or dom == "binary_tanh":
             fn = _abi.FN_GRID if dom == "binary" else _abi.FN_BINARY_TANH
             store = _abi.STORE_BIN if wbits_store == _abi.STORE_BIN else wbits_store
