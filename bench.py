@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-targets", action="store_true", help="skip the north-star target block (layer ops, other workloads)")
     ap.add_argument("--no-alternatives", action="store_true",
                     help="skip the other first-layer entries and the Model.predict figure (profiling runs)")
+    ap.add_argument("--gather-every", type=int, default=16,
+                    help="N > 1: batches of a lane whose logits go into one RCCL all-gather (measured on the single-rank "
+                         "RCCL path, headline workload: 1 -> 43.4 M, 4 -> 54.0 M, 16 -> 56.0 M img/s; no exchange 59.6 M)")
     ap.add_argument("--rehearse", action="store_true",
                     help="allow more ranks than GPUs (ranks share devices, logits exchanged over gloo)")
     return ap.parse_args(argv)
@@ -462,27 +465,35 @@ def main_rank(args):
     # ---- the product's pipeline (engine.Pipelined: one hipGraph of the forward per lane, lanes replayed round-robin
     # on their own streams; what nets.Model.predict runs on).  bench.py only adds what belongs to the measurement: the
     # logits all-gather, which stays outside the graphs on RCCL's own stream, overlapped with the next batch ----
+    # N > 1: the logits of G consecutive batches of a lane are gathered with ONE RCCL all-gather (G * 160 KB instead of G
+    # latency-bound 160 KB collectives, and one collective call of host time per G steps instead of per step: with one
+    # gather per 68 us step the host, not the GPU, sets the pace -- 43 M instead of 60 M img/s in a single-rank run of
+    # the RCCL path, 56 M with G = 16).  The last kernel of a forward writes straight into its ring slot (one hipGraph
+    # per slot), so a step is one graph launch and nothing else.  Two rings per lane alternate: a ring is only rewritten
+    # after its gather has been waited for.
+    G = max(1, args.gather_every)
+    pipelined = use_dist and backend != "gloo" and bool(args.graph)
     lanes = []
     if args.graph:
         try:
             pipe = engine.Pipelined(model, lanes=max(1, args.inflight), batch_size=N)
-            lanes = [dict(ln) for ln in pipe.lanes_for(x)]
+            if pipelined:
+                lanes = [dict(ln) for ln in pipe.lanes_for(x, slots=2 * G)]
+            else:
+                lanes = [dict(ln) for ln in pipe.lanes_for(x)]
         except Exception as exc:  # pragma: no cover
             print("hipGraph capture failed (%s); running eagerly" % exc, file=sys.stderr)
             lanes = []
     graph = lanes[0]["graph"] if lanes else None
+    pipelined = pipelined and graph is not None
     torch.cuda.synchronize()
-
-    # logits exchange (N > 1): the (B, classes) float32 block of this rank is copied to a staging
-    # buffer of its lane and all-gathered asynchronously; the next forward does not wait for it, the
-    # buffer is only reused after its gather has been waited for (stream-level wait, no host block)
-    pipelined = use_dist and backend != "gloo" and graph is not None
     for ln in lanes:
-        ln["work"] = None
         if pipelined:
-            ln["stage"] = [torch.empty_like(ln["y"]) for _ in range(2)]
-            ln["gathered"] = [torch.empty((world * ln["y"].shape[0],) + tuple(ln["y"].shape[1:]),
-                                          dtype=ln["y"].dtype, device=ln["y"].device) for _ in range(2)]
+            B = ln["y"].shape[0]
+            ln["B"] = B
+            ln["rings"] = [ln["ring"][:G * B], ln["ring"][G * B:]]
+            ln["gathered"] = [torch.empty((world * G * B,) + tuple(ln["y"].shape[1:]), dtype=ln["y"].dtype,
+                                          device=ln["y"].device) for _ in range(2)]
             ln["works"] = [None, None]
             ln["count"] = 0
     counter = [0]
@@ -494,24 +505,41 @@ def main_rank(args):
         ln = lanes[counter[0] % len(lanes)]
         counter[0] += 1
         with torch.cuda.stream(ln["stream"]):
-            ln["graph"].replay()
-            if not use_dist:
-                return
             if not pipelined:
-                shard.gather_logits(ln["y"].cpu() if backend == "gloo" else ln["y"])
+                ln["graph"].replay()
+                if use_dist:
+                    shard.gather_logits(ln["y"].cpu() if backend == "gloo" else ln["y"])
                 return
-            k = ln["count"] & 1
+            j = ln["count"] % (2 * G)              # slot inside the lane's two rings
+            k = j // G                             # which ring
             ln["count"] += 1
-            if ln["works"][k] is not None:
-                ln["works"][k].wait()
-            ln["stage"][k].copy_(ln["y"])
-            ln["works"][k] = dist.all_gather_into_tensor(ln["gathered"][k], ln["stage"][k], async_op=True)
+            if j % G == 0 and ln["works"][k] is not None:
+                ln["works"][k].wait()              # the ring is about to be rewritten: its gather must have read it
+                ln["works"][k] = None
+            if ln["direct"]:
+                ln["graphs"][j].replay()           # the last kernel writes straight into slot j
+            else:
+                ln["graph"].replay()
+                ln["ring"][j * ln["B"]:(j + 1) * ln["B"]].copy_(ln["y"], non_blocking=True)
+            if j % G == G - 1:
+                ln["works"][k] = dist.all_gather_into_tensor(ln["gathered"][k], ln["rings"][k], async_op=True)
 
     def drain():
+        """Gather what the timed steps left in a partly filled ring (every rank is at the same count: whole rings are
+        gathered, slots not yet rewritten included) and wait for every gather."""
         for ln in lanes:
+            if not pipelined:
+                continue
             with torch.cuda.stream(ln["stream"]):
+                j = ln["count"] % (2 * G)
+                if j % G != 0:
+                    k = j // G
+                    if ln["works"][k] is not None:
+                        ln["works"][k].wait()
+                    ln["works"][k] = dist.all_gather_into_tensor(ln["gathered"][k], ln["rings"][k], async_op=True)
+                    ln["count"] += G - (j % G)     # the ring counts as used up
                 for k in range(2):
-                    if pipelined and ln["works"][k] is not None:
+                    if ln["works"][k] is not None:
                         ln["works"][k].wait()
                         ln["works"][k] = None
 
@@ -553,11 +581,12 @@ def main_rank(args):
         model.check_domain()      # "image" / "fixed": every input of the run was inside the kernel's domain (raises otherwise)
 
     if pipelined and rank == 0:
-        # the gathered block must hold this rank's logits at its own offset
-        ln = lanes[(counter[0] - 1) % len(lanes)]
-        nloc = ln["y"].shape[0]
-        torch.testing.assert_close(ln["gathered"][(ln["count"] - 1) & 1][rank * nloc:(rank + 1) * nloc],
-                                   ln["y"], rtol=0, atol=0)
+        # a gathered block must hold this rank's ring at its own offset
+        torch.cuda.synchronize()
+        ln = lanes[0]
+        nloc = G * ln["B"]
+        for k in range(2):
+            torch.testing.assert_close(ln["gathered"][k][rank * nloc:(rank + 1) * nloc], ln["rings"][k], rtol=0, atol=0)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -604,6 +633,8 @@ def main_rank(args):
                        "parallelism": "dp%d" % world,
                        "dist_backend": backend if use_dist else None,
                        "rccl_world_size": world if (use_dist and backend == "nccl") else (1 if not use_dist else 0),
+                       "logits_gather": ("one all-gather per %d batches of a lane, asynchronous" % G) if pipelined
+                       else ("per batch" if use_dist else None),
                        "timed_regions": len(regions),
                        "region_ms_min_median_max": [round(min(regions) * 1e3, 4), round(dt * 1e3, 4),
                                                     round(max(regions) * 1e3, 4)],

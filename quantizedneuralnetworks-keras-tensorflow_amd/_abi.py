@@ -361,12 +361,18 @@ def conv2d_f32in(w, x, in_fn, in_bits, bn_inv=None, bn_shift=None, fn=FN_NONE, a
 
 
 def dense(w, x, x_store, x_bits, N, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
-          out_store=STORE_F32):
+          out_store=STORE_F32, out=None):
     cout = w.shape[3]
     if out_store == STORE_F32:
-        y = torch.empty((N, cout), dtype=torch.float32, device=x.device)
+        shape, dt = (N, cout), torch.float32
     else:
-        y = torch.empty((N, words(out_store, cout)), dtype=torch.int32, device=x.device)
+        shape, dt = (N, words(out_store, cout)), torch.int32
+    if out is None:
+        y = torch.empty(shape, dtype=dt, device=x.device)
+    else:
+        if tuple(out.shape) != shape or out.dtype != dt or not out.is_contiguous() or out.device != x.device:
+            raise QnnError("dense: `out` must be a contiguous %s tensor of shape %s on %s" % (dt, shape, x.device))
+        y = out
     epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, 1, out_store)
     check(load().qnn_dense_forward(w.handle, ptr(x), x_store, x_bits, N, ctypes.byref(epi), ptr(y),
                                    stream_ptr()), "qnn_dense_forward")

@@ -229,7 +229,7 @@ class FusedModel:
         st = self.steps[si]
         if st["kind"] != "conv":
             return _abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
-                              st["fn"], st["act_bits"], st["out_store"]), H, W
+                              st["fn"], st["act_bits"], st["out_store"], out=out), H, W
         u8 = si == 0 and cur.dtype == torch.uint8
         x_store = _abi.STORE_U8 if u8 else st["x_store"]
         opt = self.FIRST_LAYER_OPTION[self.first_layer] if (si == 0 and not u8) else None
@@ -268,11 +268,15 @@ class FusedModel:
                 b(stream, x_ptr if i == 0 else None, y_ptr if i == last else None)
         return plan, tuple(cur.shape), cur.dtype
 
-    def forward_from(self, s0, cur, N, H, W):
-        """Steps s0.. on `cur` (the images for s0 = 0, else the output of step s0 - 1 at H x W)."""
+    def forward_from(self, s0, cur, N, H, W, out=None):
+        """Steps s0.. on `cur` (the images for s0 = 0, else the output of step s0 - 1 at H x W).  `out`: a tensor the
+        last step writes its result into (only where no torch op follows it)."""
         log = getattr(self, "kernel_log", None)      # tests: set to a list to record the kernel of every layer
+        last = len(self.steps) - 1
+        if out is not None and self.steps[last]["softmax"]:
+            raise _abi.QnnError("forward_from: `out` needs a network that ends in a library kernel")
         for si in range(s0, len(self.steps)):
-            cur, H, W = self.run_step(si, cur, N, H, W)
+            cur, H, W = self.run_step(si, cur, N, H, W, out=out if si == last else None)
             if log is not None:
                 log.append(_abi.last_kernel())
             if self.steps[si]["softmax"]:
@@ -804,12 +808,13 @@ class Pipelined:
         self.model, self.nlanes, self.batch_size = model, int(lanes), int(batch_size)
         self._lanes = {}                     # (batch shape, dtype) -> list of lane dicts
 
-    def _capture(self, example):
-        key = (tuple(example.shape), example.dtype)
+    def _capture(self, example, slots=1):
+        key = (tuple(example.shape), example.dtype, slots)
         if key in self._lanes:
             return self._lanes[key]
         lanes = []
         cur = torch.cuda.current_stream()
+        direct = slots > 1 and isinstance(self.model, FusedModel) and not self.model.steps[-1]["softmax"]
         for _ in range(self.nlanes):
             xs = torch.empty_like(example)
             xs.copy_(example)
@@ -817,19 +822,41 @@ class Pipelined:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 for _ in range(2):           # warm-up outside capture: lazy initialisation, allocator pools
-                    self.model(xs)
+                    y0 = self.model(xs)
             cur.wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                ys = self.model(xs)
-            lanes.append(dict(stream=torch.cuda.Stream(), graph=g, x=xs, y=ys))
+            lane = dict(stream=torch.cuda.Stream(), x=xs)
+            if slots == 1:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    ys = self.model(xs)
+                lane.update(graph=g, y=ys)
+            else:
+                # `slots` result slots per lane (a ring the caller hands to one collective per `slots` batches): one
+                # graph per slot whose last kernel writes straight into the slot -- or, for engines that cannot be told
+                # where to write, ONE graph plus a copy into the slot after every replay
+                B = y0.shape[0]
+                ring = torch.empty((slots * B,) + tuple(y0.shape[1:]), dtype=y0.dtype, device=y0.device)
+                lane.update(ring=ring, direct=direct, graphs=[])
+                N, H, W, _ = example.shape
+                for j in range(slots if direct else 1):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        if direct:
+                            ys = self.model.forward_from(0, xs, N, H, W, out=ring[j * B:(j + 1) * B])
+                        else:
+                            ys = self.model(xs)
+                    lane["graphs"].append(g)
+                lane.update(graph=lane["graphs"][0], y=ys)
+            lanes.append(lane)
         torch.cuda.synchronize()
         self._lanes[key] = lanes
         return lanes
 
-    def lanes_for(self, example):
-        """The captured lanes for batches shaped like `example` (bench.py replays them directly)."""
-        return self._capture(example)
+    def lanes_for(self, example, slots=1):
+        """The captured lanes for batches shaped like `example` (bench.py replays them directly).  slots > 1: every
+        lane owns a ring of `slots` result blocks (`ring`, `graphs`, `direct`): replay `graphs[j]` to fill slot j when
+        `direct`, else replay `graph` and copy `y` into the slot."""
+        return self._capture(example, slots)
 
     def _bound_lanes(self, example):
         """Zero-copy form for FusedModel: per lane a bound launch plan (FusedModel.bind) with its own intermediate
