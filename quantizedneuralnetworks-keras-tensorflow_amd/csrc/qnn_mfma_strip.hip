@@ -23,6 +23,13 @@
 //   Cin 16: one step, kq = dx (kq = 3: zero filter);  Cin 32: (dx0 lo, dx0 hi, dx1 lo, dx1 hi), (dx2 lo, dx2 hi, 0, 0);
 //   Cin 64: one step per tap.  int4 codes are widened to code*16 in both operands (x256 folded into the power-of-two
 //   output scale), exactly as in qnn_mfma_small.hip.
+// (Round 3 measured the other cut -- lane group kq owns tap dx = kq and fetches its whole pixel with 16-byte loads, BP
+// K-steps three quarters full -- on the stride-1 kernel: Cin 32 unchanged (18.7 / 16.4 us), Cin 64 slower (16.6 against
+// 14.8 us: a fourth K-step and 30 more registers); the stride-2 kernel below keeps it, 14.0 -> 12.2 us at Cin 32.)
+// Filter rows are dealt to the NT channel tiles so that a lane's 4*NT results are CONSECUTIVE channels (tile nt, row
+// 4*kq + i  <->  channel nbase + 4*NT*kq + 4*nt + i): with NT = 2 the two 16-bit fields of a lane are one 32-bit word,
+// i.e. ONE store and ONE shortcut load per row instead of two each (round 3: the 32- and 64-channel layers ran with the
+// texture-address FIFOs full, SQ_VMEM_TA_ADDR_FIFO_FULL 2.4-2.9 M against 0.3 M on the 16-channel layers).
 // A wave computes 16*NT output channels (blockIdx.y selects the block): Cin 64 -> 64 runs as two 32-channel halves so
 // that the 18 filter fragments stay in registers.  Any width: the last strip of a row is partly out of the image (its
 // loads and stores get out-of-range offsets).
@@ -77,10 +84,11 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
         for (int st = 0; st < ST; ++st)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int woff = kok[st] ? ((nbase + nt * 16 + r) * 9 + dy * 3 + dxs[st]) * CIN + hbs[st] * 16 : (int)0x80000000;
+                const int ch = nbase + 4 * NT * (r >> 2) + 4 * nt + (r & 3);       // filter of A row r in tile nt
+                const int woff = kok[st] ? (ch * 9 + dy * 3 + dxs[st]) * CIN + hbs[st] * 16 : (int)0x80000000;
                 bw[dy][st][nt] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
             }
-    // ---- epilogue constants: this lane's channels are nbase + nt*16 + 4*kq + i ----
+    // ---- epilogue constants: this lane's channels are nbase + 4*NT*kq + 4*nt + i ----
     // Everything behind the BN is scaled by powers of two only (activation code scale m, residual post-scale): those
     // factors commute with every float32 rounding, so they are folded into the per-channel constants and the epilogue
     // is cvt, [add bias], mul, add, [fma shortcut], round, clamp per value.
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = nbase + nt * 16 + 4 * kq + i;
+            const int c = nbase + 4 * NT * kq + 4 * nt + i;
             const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
             const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
             nb[nt][i >> 1][i & 1] = BIAS ? __fdiv_rn(e.bias[c], e.scale) : 0.0f;
@@ -144,9 +152,9 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
             voff[st] = (kok[st] && px >= 0 && px < g.W) ? ((y0 - 1) * g.W + px) * PIXB + hbs[st] * 8 : (int)0x80000000;
         }
         const bool pvalid = xs + r < g.W;                                       // last strip of a ragged row
-        int ovoff = pvalid ? (y0 * g.W + xs + r) * e.ocw * 4 + nbase / 2 + kq * 2 : (int)0x80000000;      // + nt*8
-        int rvoff = RES == 2 ? (pvalid ? ((y0 * g.W + xs + r) * g.cout + nbase + 4 * kq) * 4 : (int)0x80000000)
-                             : ovoff;                                           // + nt*64 (f32) / nt*8
+        int ovoff = pvalid ? (y0 * g.W + xs + r) * e.ocw * 4 + nbase / 2 + kq * 2 * NT : (int)0x80000000;   // 2*NT bytes
+        int rvoff = RES == 2 ? (pvalid ? ((y0 * g.W + xs + r) * g.cout + nbase + 4 * NT * kq) * 4 : (int)0x80000000)
+                             : ovoff;                                           // + nt*16 (f32: the next four floats)
 
         // Loads are requested THREE rows ahead (a ring of three input-row register sets and three shortcut registers):
         // vmcnt retires in issue order, so a wave that waits for the oldest request keeps two rows of younger ones in
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
         // instruction every ~6 cycles either way, 70 % of its slots -- kept because it is what lower occupancy needs.)
         v4i X[3][ST];
         uint2 raw[3][ST];
-        uint32_t rs[3][NT];
+        uint32_t rs[3][NT];                            // packed shortcut: [.][0] holds the lane's whole 2*NT-byte field
         float4 rf[3][NT];
         auto load_row = [&](uint2 (&dst)[ST]) {
 #pragma unroll
@@ -164,12 +172,14 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
             }
         };
         auto load_res = [&](uint32_t (&ds)[NT], float4 (&df)[NT]) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if constexpr (RES == 1) ds[nt] = __builtin_amdgcn_raw_buffer_load_b16(rr, rvoff + 8 * nt, 0, 0);
-                if constexpr (RES == 2)
-                    df[nt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, rvoff + 64 * nt, 0, 0));
+            if constexpr (RES == 1) {
+                if constexpr (NT == 1) ds[0] = __builtin_amdgcn_raw_buffer_load_b16(rr, rvoff, 0, 0);
+                else ds[0] = __builtin_amdgcn_raw_buffer_load_b32(rr, rvoff, 0, 0);        // both tiles' codes in one word
             }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if constexpr (RES == 2)
+                    df[nt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, rvoff + 16 * nt, 0, 0));
             rvoff += rrowb;
         };
         load_row(raw[0]);                              // row y0 - 1
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
                     acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[2][st][nt], Xc[st], acc[nt], 0, 0, 0);
             }
             // ---- epilogue: the reference's op order, one rounding per operation ----
+            uint32_t field[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 v2f u2[2];
@@ -222,8 +233,8 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
                     u = u + nshift[nt][h];
                     if constexpr (RES == 1) {
                         // shortcut value = code * 2^-(bits-1), exact: fma(code, scale, t) IS the reference's x + y
-                        const v2f cd = {(float)((int)(rcur[nt] << (28 - 8 * h)) >> 28),
-                                        (float)((int)(rcur[nt] << (24 - 8 * h)) >> 28)};
+                        const v2f cd = {(float)((int)(rcur[0] << (28 - 8 * h - 16 * nt)) >> 28),
+                                        (float)((int)(rcur[0] << (24 - 8 * h - 16 * nt)) >> 28)};
                         u = __builtin_elementwise_fma(cd, rcoef2, u);
                     }
                     if constexpr (RES == 2) {
@@ -252,9 +263,13 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
                 uint32_t P = ((uint32_t)cb[1] << 4) | (uint32_t)cb[0];
                 P = ((uint32_t)cb[2] << 8) | P;
                 P = ((uint32_t)cb[3] << 12) | P;
-                // (2-byte accesses cost nothing here: dword stores from every other lane and dword shortcut loads measured
-                // the same 21 / 28 us on the 224^2 layers)
-                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(P ^ 0x8888u), yr, ovoff + 8 * nt, 0, 0);
+                field[nt] = P;                             // bits 16.. hold shifted bits of the magic constant
+            }
+            if constexpr (NT == 1) {
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(field[0] ^ 0x8888u), yr, ovoff, 0, 0);
+            } else {
+                static_assert(NT <= 2, "a lane's fields must fit one word");
+                __builtin_amdgcn_raw_buffer_store_b32(((field[1] << 16) | (field[0] & 0xFFFFu)) ^ 0x88888888u, yr, ovoff, 0, 0);
             }
             ovoff += orowb;
         };
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
                                                                              FastDiv fd_spr, int nch, FastDiv fd_nch,
                                                                              int rc, uint32_t img_x, uint32_t img_y) {
     constexpr int BP = CIN / 16;
-    constexpr int ST = (3 * BP + 3) / 4;
+    constexpr int ST = BP;                             // tap dx = kq, channel group st (see k_conv_strip)
     constexpr int PIXB = CIN / 2;
     const ConvGeom& g = mg.g;                          // g.H, g.W: input; g.Ho, g.Wo: output
     const int lane = threadIdx.x & 63;
@@ -296,10 +311,9 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
     bool kok[ST];
 #pragma unroll
     for (int st = 0; st < ST; ++st) {
-        const int j = 4 * st + kq;
-        kok[st] = j < 3 * BP;
-        dxs[st] = kok[st] ? j / BP : 1;
-        hbs[st] = kok[st] ? j % BP : 0;
+        kok[st] = kq < 3;
+        dxs[st] = kok[st] ? kq : 1;
+        hbs[st] = st;
     }
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
@@ -310,9 +324,11 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
         for (int st = 0; st < ST; ++st)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int woff = kok[st] ? ((nbase + nt * 16 + r) * 9 + dy * 3 + dxs[st]) * CIN + hbs[st] * 16 : (int)0x80000000;
+                const int ch = nbase + 4 * NT * (r >> 2) + 4 * nt + (r & 3);       // as in k_conv_strip: consecutive channels per lane
+                const int woff = kok[st] ? (ch * 9 + dy * 3 + dxs[st]) * CIN + hbs[st] * 16 : (int)0x80000000;
                 bw[dy][st][nt] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
             }
+    static_assert(NT == 2, "the stride-2 kernel stores one 32-bit word per lane");
     const bool binary = e.fn == QNN_FN_BINARY_TANH;
     const float cfold = binary ? 1.0f : e.act_m;
     v2f nb[NT][2], ninv[NT][2], nshift[NT][2];
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = nbase + nt * 16 + 4 * kq + i;
+            const int c = nbase + 4 * NT * kq + 4 * nt + i;
             nb[nt][i >> 1][i & 1] = BIAS ? __fdiv_rn(e.bias[c], e.scale) : 0.0f;
             ninv[nt][i >> 1][i & 1] = __fmul_rn(__fmul_rn(e.bn_inv ? e.bn_inv[c] : 1.0f, e.scale), cfold);
             nshift[nt][i >> 1][i & 1] = __fmul_rn(e.bn_inv ? e.bn_shift[c] : 0.0f, cfold);
@@ -348,26 +364,30 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
             const_cast<uint8_t*>(x) + (size_t)n * img_x, 0, (int)img_x, 0x00020000);
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
             (uint8_t*)y + (size_t)n * img_y, 0, (int)img_y, 0x00020000);
-        int voff[3][ST];
+        int voff[3];
+        const int px = 2 * (xs + r) - g.pl + kq;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int st = 0; st < ST; ++st) {
-                const int px = 2 * (xs + r) - g.pl + dxs[st];
-                voff[dy][st] = (kok[st] && px >= 0 && px < g.W && xs + r < g.Wo)
-                                   ? ((2 * y0 - g.pt + dy) * g.W + px) * PIXB + hbs[st] * 8 : (int)0x80000000;
-            }
+            voff[dy] = (kq < 3 && px >= 0 && px < g.W && xs + r < g.Wo) ? ((2 * y0 - g.pt + dy) * g.W + px) * PIXB
+                                                                        : (int)0x80000000;
         const bool pvalid = xs + r < g.Wo;
-        int ovoff = pvalid ? (y0 * g.Wo + xs + r) * e.ocw * 4 + nbase / 2 + kq * 2 : (int)0x80000000;
+        int ovoff = pvalid ? (y0 * g.Wo + xs + r) * e.ocw * 4 + nbase / 2 + kq * 2 * NT : (int)0x80000000;
         uint2 raw[2][3][ST];
         auto load_rows = [&](uint2 (&dst)[3][ST]) {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < 3; ++dy) {
+                if constexpr (BP == 1) {
+                    dst[dy][0] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xr, voff[dy], 0, 0));
+                } else {
 #pragma unroll
-                for (int st = 0; st < ST; ++st) {
-                    dst[dy][st] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xr, voff[dy][st], 0, 0));
-                    voff[dy][st] += rowb2;
+                    for (int h = 0; h < BP / 2; ++h) {
+                        const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[dy] + 16 * h, 0, 0));
+                        dst[dy][2 * h] = make_uint2(v.x, v.y);
+                        dst[dy][2 * h + 1] = make_uint2(v.z, v.w);
+                    }
                 }
+                voff[dy] += rowb2;
+            }
         };
         load_rows(raw[0]);
         auto body = [&](uint2 (&cur)[3][ST], uint2 (&nxt)[3][ST]) {
@@ -384,6 +404,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
                     for (int nt = 0; nt < NT; ++nt)
                         acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[dy][st][nt], xo, acc[nt], 0, 0, 0);
                 }
+            uint32_t field[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 v2f u2[2];
@@ -413,8 +434,9 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
                 uint32_t P = ((uint32_t)cb[1] << 4) | (uint32_t)cb[0];
                 P = ((uint32_t)cb[2] << 8) | P;
                 P = ((uint32_t)cb[3] << 12) | P;
-                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(P ^ 0x8888u), yr, ovoff + 8 * nt, 0, 0);
+                field[nt] = P;
             }
+            __builtin_amdgcn_raw_buffer_store_b32(((field[1] << 16) | (field[0] & 0xFFFFu)) ^ 0x88888888u, yr, ovoff, 0, 0);
             ovoff += orowb;
         };
         int yy = y0;
