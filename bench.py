@@ -431,9 +431,18 @@ def main_rank(args):
     if fused:
         cur, hh, ww = x, cf.dim, cf.dim
         for si, st in enumerate(model.steps):
+            kh, kw, cin, cout = st["w"].shape
+            if si == len(model.steps) - 2 and model.run_head(cur, N, hh, ww) is not None:
+                # the last conv group and the classifier run as ONE launch (qnn_conv2d_dense_forward): bytes = the conv's
+                # packed input + the float32 logits, MACs of both layers
+                dn = model.steps[-1]["w"].shape
+                nb_in = step_bytes(abi, dict(st, out_store=abi.STORE_F32, pool=1), N, hh, ww)[0] - N * hh * ww * cout * 4
+                ms, b2b, outs = time_launch(torch, lambda cur=cur, hh=hh, ww=ww: model.run_head(cur, N, hh, ww))
+                per_kernel.append(dict(kernel=abi.last_kernel(), ms=ms, b2b_ms=b2b, bytes=nb_in + N * dn[3] * 4, launches=1,
+                                       pipe="i8", macs=N * hh * ww * kh * kw * cin * cout + N * dn[2] * dn[3]))
+                break
             nbytes, ho, wo = step_bytes(abi, st, N, hh, ww, x_elem_bytes=1 if (u8 and si == 0) else 4)
             ms, b2b, outs = time_launch(torch, lambda si=si, cur=cur, hh=hh, ww=ww: model.run_step(si, cur, N, hh, ww)[0])
-            kh, kw, cin, cout = st["w"].shape
             kname = abi.last_kernel()
             # the integer first-layer kernels (uint8 entry, "image", "fixed") run the problem's MACs on the int8 pipe:
             # priced like every other integer layer, so HBM bounds them; the exact first layer is an f32-pipe kernel

@@ -139,8 +139,8 @@ int         qnn_set_conv_impl(int impl);
  * every setting, "first_fixed" does NOT (see below).
  *   "strip" (default 1): row-walking kernel for the 3x3 stride-1 int4 layers with 16 / 32 channels;
  *                        0 = the tile kernel (k_conv_mfma_small) takes them.
- *   "strip64" (default -1): the same kernel for 64-channel layers: -1 = only where a residual is merged (the LDS-weight kernel
- *                        is faster without one), 0 never, 1 always.
+ *   "strip64" (default -1): the same kernel for 64-channel layers: 0 never (the LDS-weight kernel takes them), -1 / 1 always
+ *                        (round 3: faster with and without a residual merge; pooled layers keep the LDS-weight kernel).
  *   "first_fixed" (default 0): 1 = float-input 3x3 layers with 3 channels, 64 filters of <= 4 bits and inputs in [0, 1]
  *                        run in fixed point (inputs rounded to 2^-23, exact int32 sums on the int8 matrix pipe, one
  *                        rounding): within 27 * 2^-24 + half an ulp of the REAL-number convolution, hence inside the
@@ -265,6 +265,18 @@ int qnn_conv2d_forward_f32in(const qnn_weights_t* w, const float* x, int in_fn, 
  */
 int qnn_dense_forward(const qnn_weights_t* w, const void* x, int x_store, int x_bits,
                       int N, const qnn_epilogue_t* epi, void* y, void* stream);
+
+/*
+ * The last convolution group of models/vgg.py (conv -> BN -> act -> MaxPooling2D, lines 32-37) and the classifier
+ * behind it (Flatten -> Dense -> BN, lines 38-42) in ONE launch:  y = dense(flatten(conv_group(x))), float32 (N, units).
+ * Bit-identical to qnn_conv2d_forward(wc, ..., epi_conv{out_store = QNN_STORE_I4}) followed by
+ * qnn_dense_forward(wd, ...): the activation codes never leave the chip.  Covers: int4-stored input, 3x3 stride-1 'same'
+ * conv of 64 / 128 channels into 64 filters, 2x2 pool down to a 4 x 4 map, dense 1024 -> at most 16 units prepacked for
+ * QNN_STORE_I4, float32 output without activation.  Anything else returns QNN_EUNSUPPORTED: issue the two calls.
+ */
+int qnn_conv2d_dense_forward(const qnn_weights_t* wconv, const qnn_weights_t* wdense, const void* x, int x_store,
+                             int x_bits, int N, int H, int W, const qnn_epilogue_t* epi_conv,
+                             const qnn_epilogue_t* epi_dense, float* y, void* stream);
 
 /* Name of the kernel variant the last qnn_conv2d_forward / qnn_dense_forward on
  * this thread dispatched to ("ps_bin_cw2_k3", "generic", "mfma_i8", ...). */

@@ -24,6 +24,7 @@ EXPORTS = [
     "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32", "qnn_avgpool_packed_f32",
     "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant", "qnn_weights_check",
     "qnn_conv2d_forward", "qnn_dense_forward", "qnn_conv2d_forward_f32in", "qnn_conv2d_workspace_bytes",
+    "qnn_conv2d_dense_forward",
 ]
 
 
@@ -90,6 +91,8 @@ def load():
     lib.qnn_weights_check.argtypes = [vp, vp]
     lib.qnn_conv2d_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
     lib.qnn_dense_forward.argtypes = [vp, vp, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
+    lib.qnn_conv2d_dense_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue),
+                                             ctypes.POINTER(Epilogue), vp, vp]
     lib.qnn_conv2d_workspace_bytes.argtypes = [vp, ci, ci, ci]
     lib.qnn_conv2d_workspace_bytes.restype = sz
     lib.qnn_conv2d_forward_f32in.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue), vp,
@@ -309,6 +312,43 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
     check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
                                     ptr(y), stream_ptr()), "qnn_conv2d_forward")
     return y, Ho, Wo
+
+
+QNN_EUNSUPPORTED = -2
+
+
+def conv2d_dense(wc, wd, x, x_store, x_bits, N, H, W, c_inv, c_shift, c_fn, c_act_bits, d_inv, d_shift, out=None):
+    """qnn_conv2d_dense_forward: the last conv group (2x2 pool, packed int4 codes) and the dense head behind it in one
+    launch.  Returns the (N, units) float32 logits, or None when no fused kernel covers the pair (QNN_EUNSUPPORTED)."""
+    units = wd.shape[3]
+    y = out if out is not None else torch.empty((N, units), dtype=torch.float32, device=x.device)
+    ec = make_epilogue(c_inv, c_shift, c_fn, c_act_bits, 2, STORE_I4)
+    ed = make_epilogue(d_inv, d_shift, FN_NONE, 0, 1, STORE_F32)
+    rc = load().qnn_conv2d_dense_forward(wc.handle, wd.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(ec),
+                                         ctypes.byref(ed), ptr(y), stream_ptr())
+    if rc == QNN_EUNSUPPORTED:
+        return None
+    check(rc, "qnn_conv2d_dense_forward")
+    return y
+
+
+class BoundHead:
+    """qnn_conv2d_dense_forward with everything bound once (see BoundStep)."""
+
+    def __init__(self, wc, wd, x_store, x_bits, N, H, W, c_inv, c_shift, c_fn, c_act_bits, d_inv, d_shift, x):
+        self._keep = (wc, wd, c_inv, c_shift, d_inv, d_shift, x)
+        self._ec = make_epilogue(c_inv, c_shift, c_fn, c_act_bits, 2, STORE_I4)
+        self._ed = make_epilogue(d_inv, d_shift, FN_NONE, 0, 1, STORE_F32)
+        self._x = x.data_ptr()
+        self._fn = load().qnn_conv2d_dense_forward
+        self._a = (wc.handle, wd.handle)
+        self._mid = (x_store, x_bits, N, H, W, ctypes.byref(self._ec), ctypes.byref(self._ed))
+
+    def __call__(self, stream, x_ptr=None, y_ptr=None):
+        rc = self._fn(self._a[0], self._a[1], ctypes.c_void_p(x_ptr or self._x), *self._mid, ctypes.c_void_p(y_ptr),
+                      ctypes.c_void_p(stream))
+        if rc != QNN_OK:
+            check(rc, "qnn_conv2d_dense_forward")
 
 
 class BoundStep:

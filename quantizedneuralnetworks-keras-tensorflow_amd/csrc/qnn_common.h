@@ -62,6 +62,7 @@ struct qnn_weights {
     uint8_t* d_mfma;      // int8 image [cout][kh*kw][cin] for the MFMA kernel (may alias d_packed)
     void* d_mfma_own;     // owned allocation behind d_mfma (I4 store), or nullptr
     void* d_aux;          // ternary: the 0.7*mean|W| cutoff (1 float), else nullptr
+    uint32_t* d_head;     // dense 1024 -> <= 16 int4 heads: the per-lane table of the fused conv + classifier kernel
     uint32_t* h_flag;     // domain flag (pinned, device-visible host word; qnn_weights_check) or nullptr
     uint32_t* d_flag;     // the same word through the device's address space
 };
@@ -72,6 +73,7 @@ int qnn_mfma_prepare_weights(qnn_weights* w, hipStream_t s);
 int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const void* x,
                         const qnn_weights* w, void* y, hipStream_t s, char* name, size_t name_len);
 int qnn_conv_impl_pref();
+int qnn_head_prepare(qnn_weights* w, hipStream_t s);
 int qnn_try_launch_stem(const ConvGeom& g, const EpiArgs& e, const void* x, const float* wq, void* y, hipStream_t s);
 int qnn_option(int which);
 int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "qnn_common.h"
+#include "qnn_mfma_common.h"
 
 #ifndef QNN_XNOR_U
 #define QNN_XNOR_U 16
@@ -1415,7 +1416,7 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
         }
     }
     PREPACK_HIP(hipGetLastError());
-    if (qnn_mfma_prepare_weights(w, s) != QNN_OK) {
+    if (qnn_mfma_prepare_weights(w, s) != QNN_OK || qnn_head_prepare(w, s) != QNN_OK) {
         qnn_free_weights(w);
         return QNN_EHIP;
     }
@@ -1433,6 +1434,7 @@ extern "C" int qnn_free_weights(qnn_weights_t* w) {
     if (w->d_mfma_own) (void)hipFree(w->d_mfma_own);
     if (w->d_aux) (void)hipFree(w->d_aux);
     if (w->h_flag) (void)hipHostFree(w->h_flag);
+    if (w->d_head) (void)hipFree(w->d_head);
     delete w;
     return QNN_OK;
 }
@@ -1510,6 +1512,62 @@ extern "C" int qnn_conv2d_forward_f32in(const qnn_weights_t* w, const float* x, 
     int rc = qnn_pack_f32(x, workspace, (size_t)N * H * W, w->cin, in_fn, x_bits, w->store, stream);
     if (rc != QNN_OK) return rc;
     return conv_forward(w, workspace, w->store, x_bits, N, H, W, epi, y, stream, false);
+}
+
+// The last conv group of a VGG and the classifier behind it in ONE launch (see the header).  Same result, bit for bit, as
+// qnn_conv2d_forward (packed int4 output) followed by qnn_dense_forward on the flattened tensor.
+extern "C" int qnn_conv2d_dense_forward(const qnn_weights_t* wc, const qnn_weights_t* wd, const void* x, int x_store,
+                                        int x_bits, int N, int H, int W, const qnn_epilogue_t* epi_conv,
+                                        const qnn_epilogue_t* epi_dense, float* y, void* stream) {
+    QNN_REQUIRE(wc && wd && x && y && epi_conv && epi_dense, QNN_EINVAL, "qnn_conv2d_dense_forward: null pointer");
+    QNN_REQUIRE(N >= 0 && H > 0 && W > 0, QNN_EINVAL, "qnn_conv2d_dense_forward: N=%d H=%d W=%d", N, H, W);
+    QNN_REQUIRE(wd->kh == 1 && wd->kw == 1, QNN_EINVAL, "qnn_conv2d_dense_forward: the second handle is not a dense layer");
+    if (x_store != QNN_STORE_I4 || wc->store != QNN_STORE_I4 || wd->store != QNN_STORE_I4 || !wc->d_mfma || !wd->d_head ||
+        qnn_conv_impl_pref() == 1 || epi_conv->pool != 2 || epi_conv->out_store != QNN_STORE_I4 || epi_conv->res ||
+        epi_conv->trick_s != 0.0f || epi_dense->out_store != QNN_STORE_F32 || epi_dense->fn != QNN_FN_NONE ||
+        epi_dense->res || epi_dense->pool != 1 || epi_dense->trick_s != 0.0f) {
+        qnn_set_error("qnn_conv2d_dense_forward: no fused kernel for this pair of layers");
+        return QNN_EUNSUPPORTED;
+    }
+    QNN_REQUIRE(x_bits >= 1 && x_bits <= 4, QNN_EINVAL, "qnn_conv2d_dense_forward: x_bits=%d", x_bits);
+    ConvGeom g;
+    g.N = N; g.H = H; g.W = W;
+    g.cin = wc->cin; g.cout = wc->cout; g.kh = wc->kh; g.kw = wc->kw; g.stride = wc->stride;
+    qnn_same_pad(H, wc->kh, wc->stride, wc->same_pad, &g.Ho, &g.pt);
+    qnn_same_pad(W, wc->kw, wc->stride, wc->same_pad, &g.Wo, &g.pl);
+    g.cw = wc->cw; g.kwords = wc->kwords; g.pool = 2;
+    g.Hp = g.Ho / 2; g.Wp = g.Wo / 2;
+    if (g.Hp <= 0 || g.Wp <= 0 || g.pt != 1 || g.pl != 1 || (g.cin % 64) != 0 || g.cin > 128 || g.cout != 64 ||
+        g.Hp * g.Wp * g.cout != wd->cin) {
+        qnn_set_error("qnn_conv2d_dense_forward: no fused kernel for this geometry");
+        return QNN_EUNSUPPORTED;
+    }
+    g.fd_wp = qnn_fastdiv((uint32_t)g.Wp);
+    g.fd_hp = qnn_fastdiv((uint32_t)g.Hp);
+    EpiArgs e, ed;
+    int rc = check_epilogue(wc, epi_conv, x_bits - 1, &e);
+    if (rc != QNN_OK) return rc;
+    const int abits = epi_conv->fn == QNN_FN_QUANTIZED_TANH ? epi_conv->act_bits : 1;     // codes the dense layer sees
+    rc = check_epilogue(wd, epi_dense, abits - 1, &ed);
+    if (rc != QNN_OK) return rc;
+    if (N == 0) return QNN_OK;
+    MfmaGeom mg;
+    mg.g = g; mg.kc = g.cin / 64; mg.steps = 9 * mg.kc; mg.x_pix_bytes = g.cin / 2;
+    mg.total_q = (long)N * g.Hp * g.Wp;
+    const double xb = (double)N * H * W * mg.x_pix_bytes, wb = (double)g.cout * 9 * g.cin;
+    if (xb >= 2.0e9 || mg.total_q * 4 >= 2000000000L) {
+        qnn_set_error("qnn_conv2d_dense_forward: tensor too large for one launch");
+        return QNN_EUNSUPPORTED;
+    }
+    mg.x_bytes = (uint32_t)xb; mg.w_bytes = (uint32_t)wb; mg.ablate = 0;
+    e.scale = e.scale * (1.0f / 256.0f);                    // both conv operands carry *16 (as qnn_try_launch_mfma)
+    if (qnn_launch_areg_head(mg, e, x, wc->d_mfma, wd, ed, y, (hipStream_t)stream) != 0) {
+        qnn_set_error("qnn_conv2d_dense_forward: no fused kernel for this geometry");
+        return QNN_EUNSUPPORTED;
+    }
+    qnn_set_kernel_name("mfma_i4_areg64x64+dense");
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
 }
 
 extern "C" int qnn_dense_forward(const qnn_weights_t* w, const void* x, int x_store, int x_bits,

@@ -819,10 +819,11 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                            g.pool == 1 && e.out_store == QNN_STORE_I4 && pow2 &&
                            (!e.res || (e.res_store == QNN_STORE_I4 && e.res_cw == e.ocw) ||
                             (e.res_store == QNN_STORE_F32 && e.res_cw == g.cout));
-        // Cin 64 (auto): the layers that merge a residual.  Measured, 64 x 56^2 / 4096 x 16^2 pixels: with the merge
-        // 18.8 / 65.7 us here against 36.4 / 122.8 us on the LDS-weight kernel, without it 16.3 / 54.6 against 14.1 / 47.3.
+        // Cin 64 (auto): every un-pooled layer.  Measured, 64 x 56^2 / 4096 x 16^2 pixels, round 3 (one 32-bit store and one
+        // shortcut load per row): with the merge 13.9 us here against 36.4 us on the LDS-weight kernel, without it
+        // 13.1 / 43.5 against 14.0 / 46.5 (round 2, two 16-bit accesses per row: 16.3 / 54.6 against 14.1 / 47.3).
         const int s64 = qnn_option(QNN_OPT_STRIP64);
-        const bool want = g.cin == 64 ? (s64 == 1 || (s64 < 0 && e.res != nullptr)) : true;
+        const bool want = g.cin == 64 ? s64 != 0 : true;
         if (shape && want && qnn_option(QNN_OPT_STRIP)) {
             MfmaGeom ms;
             ms.g = g; ms.kc = 1; ms.steps = 0; ms.x_pix_bytes = g.cin / 2;

@@ -356,11 +356,46 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma_wres(MfmaGeom mg, EpiArgs 
 // v_cndmask on the byte offset (out of range -> the buffer load returns zeros).
 // Three workgroups (12 waves) per CU: one wave's staging / epilogue VALU runs under
 // the other waves' MFMAs (int8 MFMA and VALU co-issue on gfx950).
-template <int XS, int OUT, int POOL, int KC>
+// HEAD (round 3): the classifier behind the last conv of a VGG (Flatten + Dense + BN, models/vgg.py:38-42) inside this
+// kernel's epilogue.  With a 4 x 4 pooled map a wave's 64-row tile IS one image, so the wave holds all 1024 activation
+// codes of its image as 2 x 8 nibbles per lane; the dense layer is then 2 x `units` v_dot8_i32_i4 per lane against a
+// per-lane weight table (k_head_table: the dense kernel's codes in this kernel's (pixel, channel) -> (lane, nibble)
+// order, kept in LDS), a 17-shuffle transpose-reduction over the wave, and one float32 epilogue on 16 lanes.  Removes
+// the dense launch (4 us of work, ~10 us of launch boundary) and the packed tensor in front of it.
+struct HeadArgs {
+    const uint32_t* tab;       // [16 units][64 lanes][2 channel halves] dwords of 8 int4 weight codes, zero past `units`
+    const float* bias;         // dense bias, BN constants (or null), as qnn_epi_value reads them
+    const float* bn_inv;
+    const float* bn_shift;
+    float scale;               // 2^-(wshift + xshift) of the dense layer
+    int units;
+    float* y;                  // (N, units) float32
+};
+
+// 16 per-lane accumulators -> their 16 wave-wide sums, one per lane: lane l ends with the sum of accumulator
+// u = 8*b0 + 4*b1 + 2*b2 + b3 (b_i = bit i of l), every lane that shares the low four bits holds the same total
+__device__ __forceinline__ int head_reduce16(const int (&a)[16], int lane, int& u_out) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    int v8[8], v4[4], v2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v8[i] = (b0 ? a[i + 8] : a[i]) + __shfl_xor(b0 ? a[i] : a[i + 8], 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v4[i] = (b1 ? v8[i + 4] : v8[i]) + __shfl_xor(b1 ? v8[i] : v8[i + 4], 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v2[i] = (b2 ? v4[i + 2] : v4[i]) + __shfl_xor(b2 ? v4[i] : v4[i + 2], 4);
+    int v = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    u_out = (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0);
+    return v;
+}
+
+template <int XS, int OUT, int POOL, int KC, bool HEAD = false>
 __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mfma_areg(MfmaGeom mg, EpiArgs e,
                                                            const uint8_t* __restrict__ x,
                                                            const uint8_t* __restrict__ wq8,
-                                                           void* __restrict__ y, int ntiles) {
+                                                           void* __restrict__ y, int ntiles, HeadArgs hd) {
+    static_assert(!HEAD || (POOL == 2 && OUT == QNN_STORE_I4), "the fused classifier sits behind pooled int4 codes");
     constexpr int TAPS = 9, S = TAPS * KC;
     static_assert(S % 3 == 0, "operand register sets rotate with period 3");
     constexpr int XCH = (XS == QNN_STORE_I8) ? 16 : 8;     // stored bytes per 16-channel chunk
@@ -417,6 +452,19 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
         fe[b].nb = __fdiv_rn(ke[b].bias, e.scale);
         fe[b].ninv = __fmul_rn(__fmul_rn(ke[b].inv, e.scale), mfold);
         fe[b].nshift = __fmul_rn(ke[b].shift, mfold);
+    }
+    // ---- fused classifier: table -> LDS (behind the filters), this lane's unit and its float32 constants ----
+    constexpr int HTAB = 9 * KC * B_STEP;                   // byte offset of the table in LDS
+    int hu = 0;
+    float hbias = 0.0f, hinv = 1.0f, hshift = 0.0f;
+    if constexpr (HEAD) {
+        for (int i = tid; i < 16 * 64 * 2; i += 256) reinterpret_cast<uint32_t*>(smem + HTAB)[i] = hd.tab[i];
+        hu = ((lane & 1) ? 8 : 0) + ((lane & 2) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 8) ? 1 : 0);
+        if (hu < hd.units) {
+            hbias = hd.bias ? hd.bias[hu] : 0.0f;
+            hinv = hd.bn_inv ? hd.bn_inv[hu] : 1.0f;
+            hshift = hd.bn_inv ? hd.bn_shift[hu] : 0.0f;
+        }
     }
     int lane_off = 0, lane_row = 0;       // packed outputs: word offset / local row of this lane's word
     if constexpr (OUT == QNN_STORE_I4) {
@@ -502,6 +550,11 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
         const long rem_l = mg.total_q - row0;
         const int rem = rem_l > TM ? TM : (int)rem_l;               // stored pixels left from row0
         uint32_t* ytile = reinterpret_cast<uint32_t*>(y) + row0 * e.ocw;   // packed outputs only
+        int dacc[16];
+        if constexpr (HEAD) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dacc[u] = 0;
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int c = nbase + b * 32 + li;
@@ -518,7 +571,14 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
                         const int mn = min(min(i0, i1), min(i2, i3));
                         tv[a * 4 + g4] = bn(ke[b].neg ? mn : mx, fe[b]);
                     }
-                if constexpr (OUT == QNN_STORE_I4) {
+                if constexpr (HEAD) {
+                    // this lane's codes of channel c at the pooled pixels 8*(j >> 2) + 2*(j & 3) + lh, j = nibble index:
+                    // two's-complement nibbles straight into v_dot8_i32_i4 against the table's nibbles of every unit
+                    const uint32_t Q = pack_scaled<4, 8>(tv, e.act_m, binary) ^ 0x88888888u;
+                    const uint32_t* trow = reinterpret_cast<const uint32_t*>(smem + HTAB) + lane * 2 + b;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) dacc[u] = __builtin_amdgcn_sdot8((int)Q, (int)trow[u * 128], dacc[u], false);
+                } else if constexpr (OUT == QNN_STORE_I4) {
                     const uint32_t P = pack_scaled<4, 8>(tv, e.act_m, binary);
                     const uint32_t Wd = transpose_nib8(P, ke[0]) ^ 0x88888888u;
                     if (lane_row < rem) ytile[lane_off + b * 4] = Wd;
@@ -612,6 +672,17 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
                 }
             }
         }
+        if constexpr (HEAD) {
+            int u;
+            const int tot = head_reduce16(dacc, lane, u);
+            if (lane < 16 && u < hd.units) {
+                // BinaryDense / QuantizedDense .call + BN, the reference's op order (as k_dense_packed)
+                float v = __fmul_rn((float)tot, hd.scale);
+                if (hd.bias) v = __fadd_rn(v, hbias);
+                if (hd.bn_inv) v = __fadd_rn(__fmul_rn(v, hinv), hshift);
+                hd.y[(long)tile * hd.units + u] = v;         // tile == image: a 4 x 4 pooled map is one 64-row tile
+            }
+        }
     };
 
     // When a wave's tile stride covers whole images (and no tile is partial) the decoded rows
@@ -696,9 +767,40 @@ void launch_areg_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const
     }();
     (void)lds_ok;
     if (mg.g.pool == 2)
-        hipLaunchKernelGGL((k_conv_mfma_areg<XS, OUT, 2, KC>), grid, block, lds, s, mg, e, (const uint8_t*)x, w, y, ntiles);
+        hipLaunchKernelGGL((k_conv_mfma_areg<XS, OUT, 2, KC>), grid, block, lds, s, mg, e, (const uint8_t*)x, w, y, ntiles, HeadArgs{});
     else
-        hipLaunchKernelGGL((k_conv_mfma_areg<XS, OUT, 1, KC>), grid, block, lds, s, mg, e, (const uint8_t*)x, w, y, ntiles);
+        hipLaunchKernelGGL((k_conv_mfma_areg<XS, OUT, 1, KC>), grid, block, lds, s, mg, e, (const uint8_t*)x, w, y, ntiles, HeadArgs{});
+}
+
+template <int KC>
+void launch_areg_head(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, const HeadArgs& hd, hipStream_t s) {
+    const int ntiles = (int)((mg.total_q * 4 + 63) / 64);
+    int gx = (((ntiles + 3) / 4 + 7) / 8) * 8;
+    if (gx > 768) gx = 768;
+    const size_t lds = (size_t)9 * KC * 64 * 64 + 16 * 64 * 2 * 4;
+    static const bool lds_ok = [] {
+        (void)hipFuncSetAttribute((const void*)k_conv_mfma_areg<QNN_STORE_I4, QNN_STORE_I4, 2, KC, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        return true;
+    }();
+    (void)lds_ok;
+    hipLaunchKernelGGL((k_conv_mfma_areg<QNN_STORE_I4, QNN_STORE_I4, 2, KC, true>), dim3((unsigned)gx, 1), dim3(256), lds, s, mg, e,
+                       (const uint8_t*)x, w, (void*)nullptr, ntiles, hd);
+}
+
+// dense int4 codes [units][1024 / 8 words] -> the per-lane table of the fused classifier (see HeadArgs)
+__global__ __launch_bounds__(256) void k_head_table(const uint32_t* __restrict__ dp, uint32_t* __restrict__ tab, int units) {
+    const int i = blockIdx.x * 256 + threadIdx.x;            // (u * 64 + lane) * 2 + b
+    if (i >= 16 * 64 * 2) return;
+    const int b = i & 1, lane = (i >> 1) & 63, u = i >> 7;
+    const int li = lane & 31, lh = lane >> 5;
+    uint32_t word = 0;
+    if (u < units)
+        for (int j = 0; j < 8; ++j) {
+            const int f = (8 * (j >> 2) + 2 * (j & 3) + lh) * 64 + b * 32 + li;     // Flatten index of (pooled pixel, channel)
+            word |= ((dp[u * 128 + (f >> 3)] >> (4 * (f & 7))) & 0xFu) << (4 * j);
+        }
+    tab[i] = word;
 }
 
 template <int XS, int KC>
@@ -764,4 +866,30 @@ int qnn_launch_wres(int x_store, const MfmaGeom& mg, const EpiArgs& e, const voi
                     void* y, hipStream_t s) {
     return x_store == QNN_STORE_I8 ? launch_wres<QNN_STORE_I8>(mg, e, x, w, y, s)
                                    : launch_wres<QNN_STORE_I4>(mg, e, x, w, y, s);
+}
+
+
+// ---- fused conv + classifier (qnn_conv2d_dense_forward): table at prepack time, launch ----
+int qnn_head_prepare(qnn_weights* w, hipStream_t s) {
+    w->d_head = nullptr;
+    if (w->kh != 1 || w->kw != 1 || w->cin != 1024 || w->cout > 16 || w->store != QNN_STORE_I4 || !w->d_packed) return QNN_OK;
+    QNN_HIP(hipMalloc((void**)&w->d_head, 16 * 64 * 2 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_head_table, dim3(8), dim3(256), 0, s, w->d_packed, w->d_head, w->cout);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+// 0 = launched.  Conv: int4 in, 3x3 stride 1 SAME, Cin 64 / 128, 64 filters, 2x2 pool, int4 codes out, 4 x 4 pooled map;
+// dense: the matching 1024 -> <= 16 head prepacked for int4.  `ed` is the dense layer's epilogue (float32 out, no fn).
+int qnn_launch_areg_head(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, const qnn_weights* wd,
+                         const EpiArgs& ed, float* y, hipStream_t s) {
+    const ConvGeom& g = mg.g;
+    if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.cout != 64 || g.pool != 2 || (mg.kc != 1 && mg.kc != 2)) return 1;
+    if (g.Hp * g.Wp != 16 || e.out_store != QNN_STORE_I4 || e.res || !wd->d_head || wd->cin != 1024) return 1;
+    HeadArgs hd;
+    hd.tab = wd->d_head; hd.bias = ed.bias; hd.bn_inv = ed.bn_inv; hd.bn_shift = ed.bn_shift;
+    hd.scale = ed.scale; hd.units = wd->cout; hd.y = y;
+    if (mg.kc == 1) launch_areg_head<1>(mg, e, x, w, hd, s);
+    else launch_areg_head<2>(mg, e, x, w, hd, s);
+    return 0;
 }

@@ -129,6 +129,7 @@ class FusedModel:
             raise ValueError("trick must be None, 'nep50' or 'legacy', got %r" % (trick,))
         self.first_layer = first_layer
         self.device = torch.device(device)
+        self.fuse_head = True                # conv group + Flatten + Dense in one launch where the library has the kernel
         self.steps = []
         self._keep = []
         groups = self._group(spec)
@@ -167,6 +168,14 @@ class FusedModel:
                     # words: the conv pads each pixel to a word boundary, the dense weights are packed as
                     # one contiguous K = H*W*C vector.  Widen the storage until the channels divide.
                     cout = op["kernel"].shape[3]
+                    kh_, kw_, cin_, _ = op["kernel"].shape
+                    if out_store == _abi.STORE_BIN and (kh_, kw_, cout) == (3, 3, 64) and cin_ in (64, 128) and \
+                            g["pool"] == 2 and g["stride"] == 1 and g["same"] and x_store == _abi.STORE_I4 and \
+                            nxt["kernel"].shape[0] == 1024 and nxt["kernel"].shape[1] <= 16 and \
+                            _abi.conv_impl() != _abi.IMPL_VALU:
+                        # +-1 codes as int4 in front of the classifier: lets the last conv group and the dense layer
+                        # run as ONE launch (qnn_conv2d_dense_forward); 8 KB instead of 2 KB per image, never stored
+                        out_store = _abi.STORE_I4
                     while cout % _abi.per_word(out_store) != 0 and out_store < _abi.STORE_I8:
                         out_store = {_abi.STORE_BIN: _abi.STORE_I4, _abi.STORE_I4: _abi.STORE_I8}[out_store]
                     if cout % _abi.per_word(out_store) != 0:
@@ -223,6 +232,26 @@ class FusedModel:
             groups.append(g)
         return groups
 
+    def _head_candidate(self):
+        """True if the last two steps are a pooled conv group with int4 output and the dense head behind it (the shape
+        qnn_conv2d_dense_forward fuses; the library decides about the exact geometry at launch)."""
+        if not self.fuse_head or len(self.steps) < 2:
+            return False
+        c, d = self.steps[-2], self.steps[-1]
+        return (c["kind"] == "conv" and d["kind"] == "dense" and c["pool"] == 2 and c["out_store"] == _abi.STORE_I4
+                and c["x_store"] == _abi.STORE_I4 and d["x_store"] == _abi.STORE_I4 and d["out_store"] == _abi.STORE_F32
+                and d["fn"] == _abi.FN_NONE and not d["softmax"] and not c["softmax"] and c["trick"] is None
+                and _abi.conv_impl() != _abi.IMPL_VALU)
+
+    def run_head(self, cur, N, H, W, out=None):
+        """The last conv group and the classifier in one launch (qnn_conv2d_dense_forward); None if the library has no
+        fused kernel for this geometry -- the caller then runs the two steps one after the other."""
+        if not self._head_candidate():
+            return None
+        c, d = self.steps[-2], self.steps[-1]
+        return _abi.conv2d_dense(c["w"], d["w"], cur, c["x_store"], c["x_bits"], N, H, W, c["inv"], c["shift"], c["fn"],
+                                 c["act_bits"], d["inv"], d["shift"], out=out)
+
     def run_step(self, si, cur, N, H, W, out=None):
         """Launch step `si` on `cur` (the images for si = 0: float32 or uint8; else the previous step's output).
         Returns (output, H, W).  forward() is this in a loop; bench.py times the steps one by one through it."""
@@ -253,7 +282,16 @@ class FusedModel:
         N, H, W, _ = example.shape
         u8 = example.dtype == torch.uint8
         cur, bound = example, []
+        nsteps = len(self.steps)
         for si, st in enumerate(self.steps):
+            if si == nsteps - 2 and si >= 1:
+                y = self.run_head(cur, N, H, W)
+                if y is not None:            # conv group + classifier in one launch: the plan ends here
+                    c, d = self.steps[-2], self.steps[-1]
+                    bound.append(_abi.BoundHead(c["w"], d["w"], c["x_store"], c["x_bits"], N, H, W, c["inv"], c["shift"],
+                                                c["fn"], c["act_bits"], d["inv"], d["shift"], cur))
+                    cur = y
+                    break
             out, H1, W1 = self.run_step(si, cur, N, H, W)
             x_store = _abi.STORE_U8 if (u8 and si == 0) else st["x_store"]
             bound.append(_abi.BoundStep(st["kind"], st["w"], x_store, st["x_bits"], N, H, W, st["inv"], st["shift"],
@@ -276,6 +314,12 @@ class FusedModel:
         if out is not None and self.steps[last]["softmax"]:
             raise _abi.QnnError("forward_from: `out` needs a network that ends in a library kernel")
         for si in range(s0, len(self.steps)):
+            if si == last - 1 and last >= 1:
+                y = self.run_head(cur, N, H, W, out=out)
+                if y is not None:
+                    if log is not None:
+                        log += [_abi.last_kernel(), "(fused into the conv)"]
+                    return y
             cur, H, W = self.run_step(si, cur, N, H, W, out=out if si == last else None)
             if log is not None:
                 log.append(_abi.last_kernel())

@@ -551,7 +551,7 @@ def test_small_channel_layers_on_the_matrix_pipe(cin, cout, hw, n):
             for act in (Q(4), Q(2), BIN_ACT):
                 want = _oracle_group(x, op, bn, act, 1)
                 got, kern = _run_group(x, Q(4), op, bn, act, 1, _abi.STORE_I4)
-                if strip and cin < 64:
+                if strip:                      # (round 3: the 64-channel layers take it too, with or without a merge)
                     assert kern == "strip_i4_c%d" % cin, kern
                 elif cin < 64 and W % 16 == 0:
                     assert kern == "mfma_i4_small_c%d" % cin, kern
@@ -566,7 +566,7 @@ def test_small_channel_layers_on_the_matrix_pipe(cin, cout, hw, n):
             _abi.set_option("strip64", s64)
             try:
                 got, kern = _run_group(x, Q(4), op2, bn, Q(4), 1, _abi.STORE_I4)
-                assert kern.startswith("strip") == (s64 == 1), (s64, kern)     # auto: only with a residual merge
+                assert kern.startswith("strip") == (s64 != 0), (s64, kern)     # auto = always for un-pooled layers (round 3)
                 np.testing.assert_array_equal(got, _oracle_group(x, op2, bn, Q(4), 1))
             finally:
                 _abi.set_option("strip64", -1)
@@ -662,10 +662,8 @@ def test_residual_fused_model(nt, wb, ab, nres):
             # (the first 32-channel block starts with a stride-2 conv; its second conv merges the
             # float32 projection shortcut, which the kernel reads directly)
             assert m.kernel_log.count("strip_i4_c32") >= 2 * nres - 1, m.kernel_log
-            # 64-channel stage: residual merges on the strip kernel, plain conv -> BN -> act layers on the LDS-weight one
-            assert "strip_i4_c64" in m.kernel_log, m.kernel_log
-            if nres > 1:
-                assert any(k.startswith("mfma_i4_areg") for k in m.kernel_log), m.kernel_log
+            # 64-channel stage: the strip kernel too (round 3), with and without a residual merge
+            assert m.kernel_log.count("strip_i4_c64") >= 2 * nres - 1, m.kernel_log
 
 
 def test_residual_fused_model_at_imagenet_geometry():
@@ -681,8 +679,16 @@ def test_residual_fused_model_at_imagenet_geometry():
     m.kernel_log = []
     got = host(m(dev(x)))
     np.testing.assert_array_equal(got, want)
-    for k in ("strip_i4_c16", "strip_i4_c32", "mfma_i4_areg64x64"):
+    for k in ("strip_i4_c16", "strip_i4_c32", "strip_i4_c64"):
         assert k in m.kernel_log, m.kernel_log
+    _abi.set_option("strip64", 0)           # the LDS-weight kernel for the plain 64-channel layers: same logits
+    try:
+        m3 = engine.ResidualFusedModel(spec)
+        m3.kernel_log = []
+        np.testing.assert_array_equal(host(m3(dev(x))), want)
+        assert "mfma_i4_areg64x64" in m3.kernel_log, m3.kernel_log
+    finally:
+        _abi.set_option("strip64", -1)
     # the tile kernel (strip switch off) gives the same logits
     _abi.set_option("strip", 0)
     try:

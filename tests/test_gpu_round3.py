@@ -151,3 +151,89 @@ def test_bench_default_line_carries_the_contract_and_the_round3_blocks():
     t = out["targets"]
     assert t["xnor_m0_hbm_frac"] > 0 and t["int8_mfma_frac"]["layers"] == 8
     assert set(t["images_per_s"]) == {"vgg64_full_bnn", "vgg_large_full_qnn_w8a8", "imagenet224_resnet10_w4a4"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# qnn_conv2d_dense_forward: last conv group + classifier in one launch
+# ---------------------------------------------------------------------------------------------------------------
+def _head_case(seed, N, cin, wkind, abits_in, act, dense_kind, units, bn_d=True):
+    from test_gpu_parity import BIN_ACT, Q, _rand_bn
+    rng = np.random.default_rng(seed)
+    in_act = Q(abits_in) if abits_in > 1 else BIN_ACT
+    x = O.run_spec([in_act], rng.standard_normal((N, 8, 8, cin)).astype(F32))
+    conv = {"op": "conv", "kind": wkind, "kernel": rng.uniform(-1, 1, (3, 3, cin, 64)).astype(F32),
+            "bias": (rng.standard_normal(64) * 0.05).astype(F32), "strides": (1, 1), "padding": "same"}
+    if wkind == "quantized":
+        conv["nb"] = 4
+    dense = {"op": "dense", "kind": dense_kind, "kernel": rng.uniform(-1, 1, (1024, units)).astype(F32),
+             "bias": (rng.standard_normal(units) * 0.1).astype(F32)}
+    if dense_kind == "quantized":
+        dense["nb"] = 4
+    spec = [conv, _rand_bn(rng, 64, 9 * cin * 0.12), act, {"op": "maxpool", "size": 2}, {"op": "flatten"}, dense]
+    if bn_d:
+        spec.append(_rand_bn(rng, units, 1024 * 0.1))
+    return x, in_act, spec
+
+
+@pytest.mark.parametrize("N", [1, 3, 257])
+@pytest.mark.parametrize("cin,wkind,abits_in,actname,dense_kind,units", [
+    (64, "quantized", 4, "q4", "quantized", 10), (64, "quantized", 4, "q2", "quantized", 16),
+    (64, "binary", 1, "bin", "binary", 10), (128, "quantized", 4, "q4", "quantized", 7),
+    (64, "quantized", 2, "q3", "binary", 1)])
+def test_fused_conv_and_classifier_equals_the_two_launches(N, cin, wkind, abits_in, actname, dense_kind, units):
+    from test_gpu_parity import BIN_ACT, Q
+    act = BIN_ACT if actname == "bin" else Q(int(actname[1]))
+    x, in_act, spec = _head_case(N * 31 + cin + units, N, cin, wkind, abits_in, act, dense_kind, units, bn_d=units != 7)
+    want = O.run_spec(spec, x)
+    # drive the ABI directly: packed int4 input -> logits
+    conv, bn_c, dense = spec[0], spec[1], spec[5]
+    bn_d = spec[6] if len(spec) > 6 else None
+    wc = engine._prepack(conv, _abi.STORE_I4, torch.device("cuda"))
+    wd = engine._prepack(dense, _abi.STORE_I4, torch.device("cuda"))
+    xp = _abi.pack(dev(x), cin, _abi.FN_GRID, abits_in, _abi.STORE_I4)
+    ci, cs = (dev(a) for a in engine.bn_constants(bn_c))
+    di, ds = (dev(a) for a in engine.bn_constants(bn_d)) if bn_d is not None else (None, None)
+    fn, ab = engine._act_code(act)
+    y = _abi.conv2d_dense(wc, wd, xp, _abi.STORE_I4, abits_in, N, 8, 8, ci, cs, fn, ab if fn == _abi.FN_QUANTIZED_TANH else 0,
+                          di, ds)
+    assert y is not None and _abi.last_kernel() == "mfma_i4_areg64x64+dense"
+    np.testing.assert_array_equal(host(y), want)
+    # ... and equals the two separate launches bit for bit
+    h, _, _ = _abi.conv2d(wc, xp, _abi.STORE_I4, abits_in, N, 8, 8, ci, cs, fn, ab if fn == _abi.FN_QUANTIZED_TANH else 0,
+                          2, _abi.STORE_I4)
+    y2 = _abi.dense(wd, h, _abi.STORE_I4, ab, N, di, ds)
+    assert torch.equal(y, y2)
+
+
+def test_fused_classifier_only_where_the_kernel_exists():
+    from test_gpu_parity import Q
+    x, in_act, spec = _head_case(5, 2, 64, "quantized", 4, Q(4), "quantized", 10)
+    wc = engine._prepack(spec[0], _abi.STORE_I4, torch.device("cuda"))
+    wd = engine._prepack(spec[5], _abi.STORE_I4, torch.device("cuda"))
+    ci, cs = (dev(a) for a in engine.bn_constants(spec[1]))
+    x16 = _abi.pack(torch.zeros((2, 16, 16, 64), device="cuda"), 64, _abi.FN_GRID, 4, _abi.STORE_I4)
+    assert _abi.conv2d_dense(wc, wd, x16, _abi.STORE_I4, 4, 2, 16, 16, ci, cs, _abi.FN_QUANTIZED_TANH, 4, None, None) is None
+    # whole networks: the headline configs take the fused head, with the same logits as without it
+    for idx in (1, 2):
+        cf = nets.baseline_config(idx)
+        sp = nets.build_spec(cf, nets.SEED_BASE + idx)
+        xi = nets.synthetic_images(cf, 9, 3)
+        m = engine.FusedModel(sp)
+        m.kernel_log = []
+        got = host(m(dev(xi)))
+        assert m.kernel_log[-2:] == ["mfma_i4_areg64x64+dense", "(fused into the conv)"], m.kernel_log
+        np.testing.assert_array_equal(got, O.run_spec(sp, xi, float_conv="device"))
+        m2 = engine.FusedModel(sp)
+        m2.fuse_head = False
+        m2.kernel_log = []
+        np.testing.assert_array_equal(host(m2(dev(xi))), got)
+        assert m2.kernel_log[-1].startswith("dense_"), m2.kernel_log
+    # VALU-only family: no matrix-pipe head
+    _abi.set_conv_impl(_abi.IMPL_VALU)
+    try:
+        m3 = engine.FusedModel(nets.build_spec(nets.baseline_config(2), 3))
+        m3.kernel_log = []
+        m3(dev(nets.synthetic_images(nets.baseline_config(2), 2, 1)))
+        assert not any("+dense" in k for k in m3.kernel_log)
+    finally:
+        _abi.set_conv_impl(_abi.IMPL_AUTO)
