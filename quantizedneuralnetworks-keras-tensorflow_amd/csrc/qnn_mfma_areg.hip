@@ -453,6 +453,9 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
         fe[b].ninv = __fmul_rn(__fmul_rn(ke[b].inv, e.scale), mfold);
         fe[b].nshift = __fmul_rn(ke[b].shift, mfold);
     }
+    // pooling takes the window's max or min by the sign of the channel's BN scale; when no channel of the slice has a
+    // negative one (the usual case) the minimum is never needed: two instructions per pooled value instead of five
+    const bool all_pos = !__any((int)(ke[0].neg || ke[1].neg));
     // ---- fused classifier: table -> LDS (behind the filters), this lane's unit and its float32 constants ----
     constexpr int HTAB = 9 * KC * B_STEP;                   // byte offset of the table in LDS
     int hu = 0;
@@ -568,8 +571,12 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
                         const int i0 = acc[a][b][4 * g4], i1 = acc[a][b][4 * g4 + 1];
                         const int i2 = acc[a][b][4 * g4 + 2], i3 = acc[a][b][4 * g4 + 3];
                         const int mx = max(max(i0, i1), max(i2, i3));
-                        const int mn = min(min(i0, i1), min(i2, i3));
-                        tv[a * 4 + g4] = bn(ke[b].neg ? mn : mx, fe[b]);
+                        if (all_pos) {                   // wave-uniform: every BN scale of this slice is >= 0
+                            tv[a * 4 + g4] = bn(mx, fe[b]);
+                        } else {
+                            const int mn = min(min(i0, i1), min(i2, i3));
+                            tv[a * 4 + g4] = bn(ke[b].neg ? mn : mx, fe[b]);
+                        }
                     }
                 if constexpr (HEAD) {
                     // this lane's codes of channel c at the pooled pixels 8*(j >> 2) + 2*(j & 3) + lh, j = nibble index:
