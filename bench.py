@@ -595,7 +595,8 @@ def main_rank(args):
         ln = lanes[0]
         nloc = G * ln["B"]
         for k in range(2):
-            torch.testing.assert_close(ln["gathered"][k][rank * nloc:(rank + 1) * nloc], ln["rings"][k], rtol=0, atol=0)
+            torch.testing.assert_close(ln["gathered"][k][rank * nloc:(rank + 1) * nloc], ln["rings"][k], rtol=0, atol=0,
+                                       equal_nan=True)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -879,7 +879,7 @@ class Pipelined:
                 # graph per slot whose last kernel writes straight into the slot -- or, for engines that cannot be told
                 # where to write, ONE graph plus a copy into the slot after every replay
                 B = y0.shape[0]
-                ring = torch.empty((slots * B,) + tuple(y0.shape[1:]), dtype=y0.dtype, device=y0.device)
+                ring = torch.zeros((slots * B,) + tuple(y0.shape[1:]), dtype=y0.dtype, device=y0.device)
                 lane.update(ring=ring, direct=direct, graphs=[])
                 N, H, W, _ = example.shape
                 for j in range(slots if direct else 1):

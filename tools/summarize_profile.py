@@ -48,7 +48,8 @@ TAG_PATTERNS = [
     (r"^mfma_f32_first_cin(\d)$", r"^k_conv_first_(lds|mfma)<\1,"),
     (r"^mfma_f32_stem_cin(\d)$", r"^k_conv_stem<\1,"),
     (r"^pw_i4_f32$", r"^k_conv_pw_f32<"),
-    (r"^mfma_i(\d)_areg64x64$", r"^k_conv_mfma_areg<\1,"),
+    (r"^mfma_i(\d)_areg64x64\+dense$", r"^k_conv_mfma_areg<\1, \d, \d, \d, (true|1)>"),
+    (r"^mfma_i(\d)_areg64x64$", r"^k_conv_mfma_areg<\1, \d, \d, \d(, (false|0))?>"),
     (r"^mfma_i(\d)_wres256x64$", r"^k_conv_mfma_wres<\1,"),
     (r"^mfma_i4_small_c(\d+)$", r"^k_conv_mfma_small<\1,"),
     (r"^mfma_i8x3_first_fixed$", r"^k_conv_first_fixed<"),
@@ -151,7 +152,7 @@ def retag(traffic_path, bench_log):
     by_tag = {}
     for tag in dict.fromkeys(tags):
         names = rocprof_names_for(tag, list(res))
-        if len(names) == 1:
+        if len(names) == 1 and res[names[0]].get("grids", 1) == 1:
             by_tag[tag] = dict(res[names[0]], rocprof_kernel=names[0])
     d["by_tag"] = by_tag
     json.dump(d, open(traffic_path, "w"), indent=1, sort_keys=True)
