@@ -314,12 +314,12 @@ def measure_targets(torch, pkg, args, budget_s=40.0):
         cf = nets.baseline_config(idx)
         spec = nets.build_spec(cf, nets.SEED_BASE + idx)
         fused = idx != 4
-        # configs 2 / 3 (CIFAR) take the images the way the headline does; VGG-large's 3 -> 256 first layer and the
-        # ResNet stem have no byte kernel: exact float32 first layer
-        model = engine.FusedModel(spec, first_layer=args.first_layer if (fused and args.first_layer != "u8") else "exact") \
-            if fused else engine.ResidualFusedModel(spec)
+        # every workload takes the images the way the headline does (VGG-large's 3 -> 256 first layer and the ResNet
+        # stem run on the un-pooled form of the byte kernel)
+        model = engine.FusedModel(spec, first_layer=args.first_layer if args.first_layer != "u8" else "exact") \
+            if fused else engine.ResidualFusedModel(spec, first_layer="image" if args.first_layer == "image" else "exact")
         n = BATCH if fused else 64
-        xi = nets.synthetic_images_u8(cf, n, nets.SEED_BASE + idx) if (fused and args.first_layer == "u8") \
+        xi = nets.synthetic_images_u8(cf, n, nets.SEED_BASE + idx) if args.first_layer == "u8" \
             else nets.synthetic_images(cf, n, nets.SEED_BASE + idx)
         x = torch.as_tensor(xi).cuda()
         nl = 3 if wl == "vgg_large_full_qnn_w8a8" else 2
@@ -388,12 +388,12 @@ def main_rank(args):
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     fused = idx != 4
     u8 = args.first_layer == "u8"
-    if not fused and args.first_layer not in ("exact", "u8"):
-        args.first_layer = "exact"                      # the residual engine's stem has no restricted-domain kernel
+    if not fused and args.first_layer == "fixed":
+        args.first_layer = "exact"                      # the residual engine's stem has no fixed-point kernel
 
     def make_model(first):
         if not fused:
-            return engine.ResidualFusedModel(spec)
+            return engine.ResidualFusedModel(spec, first_layer="image" if first == "image" else "exact")
         return engine.FusedModel(spec, first_layer="exact" if first == "u8" else first)
 
     def make_input(first, n, seed):
@@ -586,8 +586,7 @@ def main_rank(args):
         if not more:
             break
     dt = float(np.median(regions))
-    if fused:
-        model.check_domain()      # "image" / "fixed": every input of the run was inside the kernel's domain (raises otherwise)
+    model.check_domain()          # "image" / "fixed": every input of the run was inside the kernel's domain (raises otherwise)
 
     if pipelined and rank == 0:
         # a gathered block must hold this rank's ring at its own offset

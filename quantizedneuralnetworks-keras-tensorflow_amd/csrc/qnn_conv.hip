@@ -1283,6 +1283,12 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
         QNN_HIP(hipGetLastError());
         return QNN_OK;
     }
+    // opt-in: float32 images that are bytes / 255 on the byte kernels (qnn_first_u8.hip, F32IN; also the ResNet stem)
+    if (!launched && pref != 1 && !dense && x_store == QNN_STORE_F32 && qnn_option(QNN_OPT_FIRST_IMAGE) &&
+        qnn_try_launch_first_u8(g, e, x, w, y, s, true) == 0) {
+        launched = true;
+        snprintf(name, sizeof(name), "mfma_i8_first_img255");
+    }
     if (!launched && pref != 1 && !dense && x_store == QNN_STORE_F32 && qnn_try_launch_stem(g, e, x, w->d_wq, y, s) == 0) {
         launched = true;                           // float-input layer with few filters (ResNet stem)
         snprintf(name, sizeof(name), "mfma_f32_stem_cin%d", g.cin);
@@ -1373,7 +1379,7 @@ extern "C" int qnn_prepack_weights(int wkind, int wbits, float H, const float* k
         }                                                                      \
     } while (0)
     PREPACK_HIP(hipMalloc(&w->d_wq, nq * sizeof(float)));
-    if (store == QNN_STORE_F32 && kh == 3 && kw == 3 && cin == 3 && cout == 64) {
+    if (store == QNN_STORE_F32 && kh == 3 && kw == 3 && cin == 3) {
         // domain flag of the restricted-domain first-layer kernel: one word of pinned host memory the device can write
         PREPACK_HIP(hipHostMalloc((void**)&w->h_flag, sizeof(uint32_t), hipHostMallocMapped));
         *w->h_flag = 0;

@@ -257,6 +257,204 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same layer WITHOUT pooling and with packed output: the first conv of a deeper stage (VGG with nla > 1: 3 -> 64 ...
+// 256 filters, int4 or int8 codes) and the ResNet stem (3 -> 16, models/resnet.py:96-99).  Same strip walk, staging and
+// MFMA; every conv position is stored, so the epilogue runs on all 2048 results of a step (not on 512 pooled ones) and
+// the offset term 128 * sum k is added as an integer (an 8-bit filter's sum does not fit the sixteen spare bytes).
+// A wave computes NBLK blocks of 16 filters (blockIdx.y selects the slice of 16 * NBLK).  Packing: int8 -- a 4 x 4 byte
+// transpose over a lane quad leaves lane (r & 3) = position with four consecutive filters; int4 -- an 8 x 8 nibble
+// transpose over a lane octet pairs two filter blocks (NBLK = 4) or the step's two tiles (NBLK = 1) so that every lane
+// ends with one pixel's eight consecutive channels.  One dword store per lane and group.
+template <int OUT, int NBLK, bool BIN, bool F32IN>
+__global__ __launch_bounds__(256, 3) void k_conv_first_u8_full(ConvGeom g, EpiArgs e, const void* __restrict__ x,
+                                                                const float* __restrict__ wq, void* __restrict__ y,
+                                                                int ntasks, int spr, FastDiv fd_spr, int nch, FastDiv fd_nch,
+                                                                int rc, uint32_t img_x, float wscale, float D,
+                                                                uint32_t* __restrict__ domain_flag) {
+    static_assert(OUT == QNN_STORE_I4 || OUT == QNN_STORE_I8, "packed outputs");
+    static_assert(NBLK == 1 || NBLK == 4, "16 or 64 filters per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem_u8[];
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int cbase = blockIdx.y * (16 * NBLK);
+    uint32_t* lds = reinterpret_cast<uint32_t*>(smem_u8) + wave * kWaveLdsU;
+    uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
+    uint4* tab = reinterpret_cast<uint4*>(smem_u8 + 4 * kWaveLdsU * 4);      // [filter block][lane][2]
+    for (int i = lane; i < kWaveLdsU; i += 64) lds[i] = 0x80808080u;
+
+    if (wave < NBLK) {
+        const int c = cbase + wave * 16 + r;
+        const float bias = e.bias ? e.bias[c] : 0.0f;
+        const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
+        const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
+        const float* wrow = wq + (size_t)c * 27 + (kq < 3 ? kq : 2) * 9;
+        int part = 0;
+        uint32_t wd[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int code = (int)rintf(__fmul_rn(wrow[i], wscale));
+            if (kq == 3) code = 0;
+            part += code;
+            wd[i / 3] |= (uint32_t)(code & 0xFF) << (8 * (i % 3));
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const double m = e.fn == QNN_FN_QUANTIZED_TANH ? (double)e.act_m : 1.0;
+        const float A = (float)((double)inv * m / (double)D);
+        const float B = (float)(((double)bias * (double)inv + (double)shift) * m);
+        tab[(wave * 64 + lane) * 2] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        tab[(wave * 64 + lane) * 2 + 1] = make_uint4(__float_as_uint(A), __float_as_uint(B), (uint32_t)(128 * part), 0u);
+    }
+    __syncthreads();
+    v4i bw[NBLK];
+    float fa[NBLK], fb[NBLK];
+    int c0[NBLK];
+#pragma unroll
+    for (int nt = 0; nt < NBLK; ++nt) {
+        const uint4 t0 = tab[(nt * 64 + lane) * 2], t1 = tab[(nt * 64 + lane) * 2 + 1];
+        bw[nt] = __builtin_bit_cast(v4i, t0);
+        fa[nt] = __uint_as_float(t1.x); fb[nt] = __uint_as_float(t1.y); c0[nt] = (int)t1.z;
+    }
+    LaneEpi ke;
+    lane_epi_init<OUT>(ke, e, r, r);
+    const int py = (r >> 1) & 1, px = r & 1, w = r >> 2;
+    const bool kconst = kq == 3;
+    const int ab0 = kconst ? kConstU : ((py + kq) & 3) * kRowPitchU + 2 * w + px;
+    const int ab1 = kconst ? kConstU : ((2 + py + kq) & 3) * kRowPitchU + 2 * w + px;
+    const int tstep = kconst ? 0 : 8;
+    const int e0row = lane >= 54 ? 1 : 0, e0rem = lane - 54 * e0row;
+    const int e0px = e0rem / 3, e0ch = e0rem - 3 * e0px;
+    const bool e1ok = lane < 44;
+    const int e1rem = e1ok ? lane + 10 : 0;
+    const int e1px = e1rem / 3, e1ch = e1rem - 3 * e1px;
+    const int st0 = e0row * (kRowPitchU * 4) + e0px * 4 + e0ch;
+    const int st1 = e1ok ? kRowPitchU * 4 + e1px * 4 + e1ch : kRowPitchU * 4 + 30 * 4;
+    constexpr int EB = F32IN ? 4 : 1;
+    const int rowb = g.W * 3 * EB;
+    bool bad = false;
+    // ---- where this lane's packed word of a group goes: position jj of window kq (tile t: + 8 columns) ----
+    const int jj = (OUT == QNN_STORE_I8) ? (r & 3) : (r & 3);          // after the transposes a lane holds position r & 3
+    const int pixb = e.ocw * 4;                                        // bytes per stored pixel
+    // int8: four consecutive filters from r & ~3;  int4: eight from r & 8, block (or tile) selected by bit 2 of r
+    const int chan_b = (OUT == QNN_STORE_I8) ? (r & ~3) : ((r & 8) >> 1);
+    const int hi = (r >> 2) & 1;                                       // int4: second block / second tile of the pair
+
+    for (int task = wid; task < ntasks; task += nw) {
+        const uint32_t rest = qnn_div((uint32_t)task, fd_nch);
+        const int chunk = task - (int)rest * nch;
+        const int n = (int)qnn_div(rest, fd_spr);
+        const int xs = ((int)rest - n * spr) * 16;
+        const int rp0 = chunk * rc, rp1 = min(rp0 + rc, g.H / 2);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            (uint8_t*)const_cast<void*>(x) + (size_t)n * img_x, 0, (int)img_x, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<uint8_t*>(y) + (size_t)n * g.H * g.W * pixb, 0, g.H * g.W * pixb, 0x00020000);
+        // byte offset of this lane's word for tile 0 of conv row pair 0 (NBLK = 1, int4: the lane's tile is `hi`)
+        const int ycol = xs + 2 * kq + (jj & 1) + ((OUT == QNN_STORE_I4 && NBLK == 1) ? 8 * hi : 0);
+        const int ylane = ((jj >> 1) * g.W + ycol) * pixb + cbase * (OUT == QNN_STORE_I8 ? 1 : 0) + (OUT == QNN_STORE_I4 ? cbase / 2 : 0) + chan_b;
+        const int yrow2 = 2 * g.W * pixb;                               // two conv rows per step
+        const int c0col = xs - 1 + e0px, c1col = xs - 1 + e1px;
+        const int v0 = (c0col >= 0 && c0col < g.W) ? (c0col * 3 + e0ch) * EB + e0row * rowb : (int)0x80000000;
+        const int v1 = (e1ok && c1col >= 0 && c1col < g.W) ? (c1col * 3 + e1ch) * EB + rowb : (int)0x80000000;
+        auto stage_load = [&](int row, uint32_t& b0, uint32_t& b1) {
+            const int so = row * rowb;
+            if constexpr (F32IN) {
+                b0 = __builtin_amdgcn_raw_buffer_load_b32(xr, v0 + so, 0, 0);
+                b1 = __builtin_amdgcn_raw_buffer_load_b32(xr, v1 + so, 0, 0);
+            } else {
+                b0 = __builtin_amdgcn_raw_buffer_load_b8(xr, v0 + so, 0, 0);
+                b1 = __builtin_amdgcn_raw_buffer_load_b8(xr, v1 + so, 0, 0);
+            }
+        };
+        auto stage_write = [&](auto slotc, uint32_t b0, uint32_t b1) {
+            constexpr int SB = decltype(slotc)::value * (kRowPitchU * 4);
+            if constexpr (F32IN) {
+                b0 = image_byte(__uint_as_float(b0), bad);
+                b1 = image_byte(__uint_as_float(b1), bad);
+            }
+            ldsb[st0 + SB] = (uint8_t)(b0 ^ 0x80u);
+            ldsb[st1 + SB] = (uint8_t)(b1 ^ 0x80u);
+        };
+        const int yy_first = 2 * rp0;
+        uint32_t fa0, fa1, fb0, fb1, fc0, fc1;
+        stage_load(yy_first - 1, fa0, fa1);
+        stage_load(yy_first + 1, fb0, fb1);
+        stage_load(yy_first + 3, fc0, fc1);
+        stage_write(std::integral_constant<int, 0>{}, fa0, fa1);
+
+        auto step = [&](auto parc, int rp) {
+            constexpr int PAR = decltype(parc)::value;
+            const int yy0 = 2 * rp;
+            stage_write(std::integral_constant<int, PAR ? 0 : 2>{}, fb0, fb1);
+            fb0 = fc0; fb1 = fc1;
+            stage_load(yy0 + 5, fc0, fc1);
+            const uint32_t* abase = lds + (PAR ? ab1 : ab0);
+            v4i A[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t* p = abase + tstep * t;
+                A[t] = __builtin_bit_cast(v4i, make_uint4(p[0], p[1], p[2], p[3]));
+            }
+            const v4i z = {0, 0, 0, 0};
+            const int srow = rp * yrow2;                            // scalar offset of the step's rows
+            // t = fma(S, A, B) of the four positions of window kq for filter block nt (pre-scaled by the code scale)
+            auto values = [&](const v4i& a, int nt, float* tv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tv[i] = __fmaf_rn((float)(a[i] + c0[nt]), fa[nt], fb[nt]);
+            };
+            if constexpr (OUT == QNN_STORE_I8) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NBLK; ++nt) {
+                        const v4i a = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], bw[nt], z, 0, 0, 0);
+                        float tv[4];
+                        values(a, nt, tv);
+                        const uint32_t P = pack_scaled<8, 4>(tv, e.act_m, BIN);
+                        const uint32_t Wd = transpose_byte4(P, ke) ^ 0x80808080u;
+                        __builtin_amdgcn_raw_buffer_store_b32(Wd, yr, ylane + (8 * t) * pixb + nt * 16, srow, 0);
+                    }
+            } else if constexpr (NBLK == 4) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int np = 0; np < 2; ++np) {                // filter blocks 2*np, 2*np + 1 share a word
+                        const v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], bw[2 * np], z, 0, 0, 0);
+                        const v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[t], bw[2 * np + 1], z, 0, 0, 0);
+                        float tv[8];
+                        values(a0, 2 * np, tv);
+                        values(a1, 2 * np + 1, tv + 4);
+                        const uint32_t P = pack_scaled<4, 8>(tv, e.act_m, BIN);
+                        const uint32_t Wd = transpose_nib8(P, ke) ^ 0x88888888u;
+                        __builtin_amdgcn_raw_buffer_store_b32(Wd, yr, ylane + (8 * t) * pixb + (2 * np + hi) * 8, srow, 0);
+                    }
+            } else {
+                const v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], bw[0], z, 0, 0, 0);      // tile 0, tile 1
+                const v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], bw[0], z, 0, 0, 0);
+                float tv[8];
+                values(a0, 0, tv);
+                values(a1, 0, tv + 4);
+                const uint32_t P = pack_scaled<4, 8>(tv, e.act_m, BIN);
+                const uint32_t Wd = transpose_nib8(P, ke) ^ 0x88888888u;
+                __builtin_amdgcn_raw_buffer_store_b32(Wd, yr, ylane, srow, 0);
+            }
+        };
+        int rp = rp0;
+        for (; rp + 2 <= rp1; rp += 2) {
+            step(std::integral_constant<int, 0>{}, rp);
+            step(std::integral_constant<int, 1>{}, rp + 1);
+        }
+        if (rp < rp1) step(std::integral_constant<int, 0>{}, rp);
+    }
+    if constexpr (F32IN) {
+        if (bad) *domain_flag = 1u;
+    }
+}
+
 }  // namespace
 
 // 0 = launched.  3x3, stride 1, SAME, 3 input channels, 64 filters of <= 7 bits (or binary), W % 16 == 0, H even;
@@ -264,17 +462,23 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
 int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                             hipStream_t s, bool f32in) {
     if (f32in && !w->d_flag) return 1;                           // no flag word, no restricted-domain kernel
-    if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.cin != 3 || g.cout != 64 || e.res) return 1;
+    if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.cin != 3 || e.res) return 1;
     if ((g.W % 16) != 0 || (g.H % 2) != 0 || !w->d_wq) return 1;
-    // weight codes = value * 2^wshift: binary (+-1, H = 1) or quantized to <= 7 bits (|code| <= 64: the negated filter
-    // still fits a signed byte and sixteen bytes hold -sum k)
+    // weight codes = value * 2^wshift: binary (+-1, H = 1) or quantized (pooled form: <= 7 bits, |code| <= 64 -- the negated
+    // filter still fits a signed byte and sixteen bytes hold -sum k; un-pooled packed form: <= 8 bits)
     if (w->wkind == QNN_W_BINARY ? (w->H != 1.0f || w->wshift != 0)
-                               : (w->wkind != QNN_W_QUANT || w->wshift < 1 || w->wshift > 6)) return 1;
-    const bool fused = g.pool == 2 && e.out_store == QNN_STORE_I4 &&
+                               : (w->wkind != QNN_W_QUANT || w->wshift < 1 || w->wshift > 7)) return 1;
+    const bool small_codes = w->wshift <= 6;
+    const bool fused = g.cout == 64 && small_codes && g.pool == 2 && e.out_store == QNN_STORE_I4 &&
                        ((e.fn == QNN_FN_QUANTIZED_TANH && e.act_m <= 8.0f) || e.fn == QNN_FN_BINARY_TANH);
-    const bool rawf = g.pool == 1 && e.out_store == QNN_STORE_F32 &&
+    const bool rawf = g.cout == 64 && small_codes && g.pool == 1 && e.out_store == QNN_STORE_F32 &&
                       (e.fn == QNN_FN_NONE || e.fn == QNN_FN_QUANTIZED_TANH || e.fn == QNN_FN_BINARY_TANH);
-    if (!fused && !rawf) return 1;
+    // un-pooled packed output (k_conv_first_u8_full): 16 filters (ResNet stem) or a multiple of 64
+    const bool full = g.pool == 1 && (e.out_store == QNN_STORE_I4 || e.out_store == QNN_STORE_I8) &&
+                      (g.cout == 16 || (g.cout % 64) == 0) &&
+                      ((e.fn == QNN_FN_QUANTIZED_TANH && e.act_m <= (e.out_store == QNN_STORE_I4 ? 8.0f : 128.0f)) ||
+                       e.fn == QNN_FN_BINARY_TANH);
+    if (!fused && !rawf && !full) return 1;
     const float wscale = (float)(1 << w->wshift);
     const int spr = g.W / 16;
     const double img_x = (double)g.H * g.W * 3 * (f32in ? 4 : 1);
@@ -298,6 +502,29 @@ int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, 
     if (blocks > blocks_cap) blocks = blocks_cap;
     const dim3 grid((unsigned)blocks), block(256);
     const size_t lds = (size_t)4 * kWaveLdsU * 4 + 4 * 64 * 2 * 16;
+    if (full && !fused) {
+        if ((double)g.H * g.W * e.ocw * 4.0 >= 2.0e9) return 1;
+        const int nblk = g.cout == 16 ? 1 : 4;
+        const int gy = g.cout / (16 * nblk);
+        long bx = blocks_cap / gy > 0 ? blocks_cap / gy : 1;
+        if (bx > (ntasks_l + 3) / 4) bx = (ntasks_l + 3) / 4;
+        const dim3 fgrid((unsigned)bx, (unsigned)gy);
+        const bool bin = e.fn == QNN_FN_BINARY_TANH;
+#define U8_FULL(OUT_, NB_, BIN_, F32_)                                                                                      \
+        hipLaunchKernelGGL((k_conv_first_u8_full<OUT_, NB_, BIN_, F32_>), fgrid, block, lds, s, g, e, x, w->d_wq, y,         \
+                           (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),       \
+                           best_rc, (uint32_t)img_x, wscale, D, w->d_flag)
+#define U8_FULL_B(OUT_, NB_)                                                                                                \
+        do {                                                                                                               \
+            if (bin) { if (f32in) U8_FULL(OUT_, NB_, true, true); else U8_FULL(OUT_, NB_, true, false); }                   \
+            else { if (f32in) U8_FULL(OUT_, NB_, false, true); else U8_FULL(OUT_, NB_, false, false); }                     \
+        } while (0)
+        if (e.out_store == QNN_STORE_I8) { if (nblk == 1) U8_FULL_B(QNN_STORE_I8, 1); else U8_FULL_B(QNN_STORE_I8, 4); }
+        else { if (nblk == 1) U8_FULL_B(QNN_STORE_I4, 1); else U8_FULL_B(QNN_STORE_I4, 4); }
+#undef U8_FULL_B
+#undef U8_FULL
+        return 0;
+    }
 #define U8_LAUNCH(OUT_, POOL_, BIN_)                                                                                       \
     do {                                                                                                                   \
         if (f32in)                                                                                                         \

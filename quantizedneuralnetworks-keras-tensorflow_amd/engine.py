@@ -545,7 +545,13 @@ class ResidualFusedModel:
     float32 torch ops on unpacked tensors.
     """
 
-    def __init__(self, spec, device="cuda"):
+    def __init__(self, spec, device="cuda", first_layer="exact"):
+        """first_layer: kernel for float32 images in front of the first (3-channel) conv, as engine.FusedModel:
+        "exact" (default) or "image" (float32 bytes / 255 recognised as bytes; domain flag -> check_domain()).  uint8
+        images always take the typed QNN_STORE_U8 entry."""
+        if first_layer not in ("exact", "image"):
+            raise ValueError("first_layer must be 'exact' or 'image', got %r" % (first_layer,))
+        self.first_layer = first_layer
         self.device = torch.device(device)
         self.spec = spec
         self.names = [op.get("dst", "t%d" % i) for i, op in enumerate(spec)]
@@ -617,8 +623,23 @@ class ResidualFusedModel:
                     out.append(self.spec[ci])
         return out
 
+    def check_domain(self):
+        """Synchronise and raise QnnError if the "image" first layer met a float32 input that is not a byte / 255."""
+        for w in self._w.values():
+            if w.shape[2] <= 4 and w.store == _abi.STORE_F32:
+                w.check()
+
     # ---- evaluation --------------------------------------------------------------
     def forward(self, x):
+        if self.first_layer == "image" and isinstance(x, torch.Tensor) and x.dtype != torch.uint8:
+            _abi.set_option("first_image", 1)      # only float32-input (3-channel) convs look at it
+            try:
+                return self._forward(x)
+            finally:
+                _abi.set_option("first_image", 0)
+        return self._forward(x)
+
+    def _forward(self, x):
         x = (_abi.require_cuda_u8(x, "ResidualFusedModel.forward")
              if isinstance(x, torch.Tensor) and x.dtype == torch.uint8
              else _abi.require_cuda(x, "ResidualFusedModel.forward"))

@@ -279,8 +279,8 @@ class Model:
         self.cf, self.spec = cf, spec
         try:
             self.engine = engine.FusedModel(spec, device, first_layer=first_layer)     # chains (VGG)
-        except _abi.NotFusable:
-            self.engine = engine.ResidualFusedModel(spec, device)   # residual / non-fusable topologies
+        except _abi.NotFusable:                                     # residual / non-fusable topologies
+            self.engine = engine.ResidualFusedModel(spec, device, first_layer="image" if first_layer == "image" else "exact")
         self.layers = [op for op in spec if op["op"] in ("conv", "dense")]
         self.lanes = int(lanes)
         self._pipes = {}

@@ -173,7 +173,7 @@ def test_vgg_configs_on_uint8_images_bit_exact_vs_specification(idx):
     m = engine.FusedModel(spec)
     m.kernel_log = []
     got = host(m(dev(xu8)))
-    assert m.kernel_log[0] == ("mfma_i8_first_u8" if idx else "generic_u8")
+    assert m.kernel_log[0] == ("mfma_i8_first_u8" if idx else "generic_u8")       # MNIST: one channel, 28 wide
     want = O.run_spec_u8(spec, xu8)
     np.testing.assert_array_equal(got, want)
     # the residual engine fuses the same conv + BN + activation group behind the bytes: same bits
@@ -195,7 +195,7 @@ def test_resnet_on_uint8_images():
     m = engine.ResidualFusedModel(spec)
     m.kernel_log = []
     got = host(m(dev(xu8)))
-    assert m.kernel_log[0] == "generic_u8"
+    assert m.kernel_log[0] == "mfma_i8_first_u8"            # the stem on the byte kernel (un-pooled int4 output)
     np.testing.assert_array_equal(got, O.run_spec_u8(spec, xu8))
 
 
@@ -432,3 +432,74 @@ def test_faithful_output_trick_layer_level_and_its_limits():
         _run_u8_trick = _abi.conv2d(engine._prepack(_case("q4_32", (1, 16, 16, 3), "quantized", 4)[2], _abi.STORE_F32,
                                                     torch.device("cuda")),
                                     dev(np.zeros((1, 16, 16, 3), np.uint8)), _abi.STORE_U8, 0, 1, 16, 16, trick=(0.5, 2.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# un-pooled packed outputs of the byte kernels: first conv of a deeper VGG stage (64 ... 256 filters), ResNet stem (16)
+# ---------------------------------------------------------------------------------------------------------------
+FULL_CASES = [(16, "quantized", 4, Q(4), _abi.STORE_I4), (16, "binary", None, BIN_ACT, _abi.STORE_I4),
+              (64, "quantized", 4, Q(4), _abi.STORE_I4), (64, "quantized", 2, Q(2), _abi.STORE_I4),
+              (128, "binary", None, BIN_ACT, _abi.STORE_I4), (256, "quantized", 8, Q(8), _abi.STORE_I8),
+              (64, "quantized", 4, Q(8), _abi.STORE_I8), (16, "quantized", 4, Q(5), _abi.STORE_I8),
+              (64, "binary", None, BIN_ACT, _abi.STORE_I8)]
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32, 3), (1, 34, 16, 3), (3, 2, 48, 3)], ids=["16x32", "34x16", "2x48"])
+@pytest.mark.parametrize("case", FULL_CASES, ids=["c%d_%s%s_s%d" % (c[0], c[1][0], c[2] or "", c[4]) for c in FULL_CASES])
+def test_u8_unpooled_packed_outputs_on_the_byte_kernel(case, shape):
+    cout, kind, nb, act, store = case
+    rng, xu8, op = _case("full_%d_%s_%s" % (cout, kind, shape), shape, kind, nb, cout)
+    bn = _rand_bn(rng, cout, 27 * 0.3)
+    want = _spec_u8(xu8, op, bn, act, 1)
+    got, kern = _run_u8(xu8, op, bn, act, 1, store)
+    assert kern == "mfma_i8_first_u8"
+    np.testing.assert_array_equal(got, want)
+    # float32 bytes / 255 through the "image" entry: the same kernel, the same bits
+    x = (xu8.astype(F32) / F32(255)).astype(F32)
+    N, H, W, _ = shape
+    w = engine._prepack(op, _abi.STORE_F32, torch.device("cuda"))
+    inv, shift = (dev(a) for a in engine.bn_constants(bn))
+    fn, ab = engine._act_code(act)
+    _abi.set_option("first_image", 1)
+    try:
+        y, ho, wo = _abi.conv2d(w, dev(x), _abi.STORE_F32, 0, N, H, W, inv, shift, fn,
+                                ab if fn == _abi.FN_QUANTIZED_TANH else 0, 1, store)
+        assert _abi.last_kernel() == "mfma_i8_first_img255"
+    finally:
+        _abi.set_option("first_image", 0)
+    w.check()
+    np.testing.assert_array_equal(host(_abi.unpack(y, N * ho * wo, cout, store, ab if ab else 1)).reshape(N, ho, wo, cout), want)
+
+
+def test_resnet_and_deep_vgg_take_the_byte_kernels():
+    """ResNet stem (3 -> 16, un-pooled int4) and VGG-large's first layer (3 -> 256, 8-bit weights, un-pooled int8) on
+    uint8 images and on float32 bytes / 255 (first_layer="image"): whole networks, bit-exact vs the specification."""
+    cf = nets.Config(network_type="full-qnn", wbits=4, abits=4, architecture="RESNET", nres=1, dim=32)
+    spec = nets.build_spec(cf, 3)[:-1]
+    xu8 = nets.synthetic_images_u8(cf, 3, 3)
+    want = O.run_spec_u8(spec, xu8)
+    m = engine.ResidualFusedModel(spec)
+    m.kernel_log = []
+    np.testing.assert_array_equal(host(m(dev(xu8))), want)
+    assert m.kernel_log[0] == "mfma_i8_first_u8", m.kernel_log[:2]
+    mi = engine.ResidualFusedModel(spec, first_layer="image")
+    mi.kernel_log = []
+    x = (xu8.astype(F32) / F32(255)).astype(F32)
+    np.testing.assert_array_equal(host(mi(dev(x))), want)
+    assert mi.kernel_log[0] == "mfma_i8_first_img255", mi.kernel_log[:2]
+    mi.check_domain()
+    xb = x.copy()
+    xb[1, 2, 3, 0] = 0.123
+    mi(dev(xb))
+    with pytest.raises(_abi.QnnError, match="outside its domain"):
+        mi.check_domain()
+    # VGG-large 8/8 (BASELINE config 4), two images
+    cf = nets.baseline_config(3)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 3)
+    xu8 = nets.synthetic_images_u8(cf, 2, 7)
+    want = O.run_spec_u8(spec, xu8)
+    for first, xin, tag in (("exact", xu8, "mfma_i8_first_u8"), ("image", (xu8.astype(F32) / F32(255)).astype(F32), "mfma_i8_first_img255")):
+        m = engine.FusedModel(spec, first_layer=first)
+        m.kernel_log = []
+        np.testing.assert_array_equal(host(m(dev(xin))), want)
+        assert m.kernel_log[0] == tag, m.kernel_log[:2]
