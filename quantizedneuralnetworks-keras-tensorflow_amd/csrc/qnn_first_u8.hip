@@ -267,8 +267,9 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
 // transpose over a lane quad leaves lane (r & 3) = position with four consecutive filters; int4 -- an 8 x 8 nibble
 // transpose over a lane octet pairs two filter blocks (NBLK = 4) or the step's two tiles (NBLK = 1) so that every lane
 // ends with one pixel's eight consecutive channels.  One dword store per lane and group.
+// (16 filters per wave = two MFMAs per step: little to overlap inside a wave, so that form runs six workgroups per CU)
 template <int OUT, int NBLK, bool BIN, bool F32IN>
-__global__ __launch_bounds__(256, 3) void k_conv_first_u8_full(ConvGeom g, EpiArgs e, const void* __restrict__ x,
+__global__ __launch_bounds__(256, (NBLK == 1 ? 6 : 3)) void k_conv_first_u8_full(ConvGeom g, EpiArgs e, const void* __restrict__ x,
                                                                 const float* __restrict__ wq, void* __restrict__ y,
                                                                 int ntasks, int spr, FastDiv fd_spr, int nch, FastDiv fd_nch,
                                                                 int rc, uint32_t img_x, float wscale, float D,
@@ -469,24 +470,28 @@ int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, 
     if (w->wkind == QNN_W_BINARY ? (w->H != 1.0f || w->wshift != 0)
                                : (w->wkind != QNN_W_QUANT || w->wshift < 1 || w->wshift > 7)) return 1;
     const bool small_codes = w->wshift <= 6;
-    const bool fused = g.cout == 64 && small_codes && g.pool == 2 && e.out_store == QNN_STORE_I4 &&
-                       ((e.fn == QNN_FN_QUANTIZED_TANH && e.act_m <= 8.0f) || e.fn == QNN_FN_BINARY_TANH);
+    const bool ok_fused = g.cout == 64 && small_codes && g.pool == 2 && e.out_store == QNN_STORE_I4 &&
+                          ((e.fn == QNN_FN_QUANTIZED_TANH && e.act_m <= 8.0f) || e.fn == QNN_FN_BINARY_TANH);
     const bool rawf = g.cout == 64 && small_codes && g.pool == 1 && e.out_store == QNN_STORE_F32 &&
                       (e.fn == QNN_FN_NONE || e.fn == QNN_FN_QUANTIZED_TANH || e.fn == QNN_FN_BINARY_TANH);
     // un-pooled packed output (k_conv_first_u8_full): 16 filters (ResNet stem) or a multiple of 64
-    const bool full = g.pool == 1 && (e.out_store == QNN_STORE_I4 || e.out_store == QNN_STORE_I8) &&
-                      (g.cout == 16 || (g.cout % 64) == 0) &&
-                      ((e.fn == QNN_FN_QUANTIZED_TANH && e.act_m <= (e.out_store == QNN_STORE_I4 ? 8.0f : 128.0f)) ||
-                       e.fn == QNN_FN_BINARY_TANH);
-    if (!fused && !rawf && !full) return 1;
+    const bool ok_full = g.pool == 1 && (e.out_store == QNN_STORE_I4 || e.out_store == QNN_STORE_I8) &&
+                         (g.cout == 16 || (g.cout % 64) == 0) &&
+                         ((e.fn == QNN_FN_QUANTIZED_TANH && e.act_m <= (e.out_store == QNN_STORE_I4 ? 8.0f : 128.0f)) ||
+                          e.fn == QNN_FN_BINARY_TANH);
+    if (!ok_fused && !rawf && !ok_full) return 1;
     const float wscale = (float)(1 << w->wshift);
     const int spr = g.W / 16;
     const double img_x = (double)g.H * g.W * 3 * (f32in ? 4 : 1);
     const float D = 255.0f * wscale;                             // the divisor of the affine map (qnn_abi.h)
     if (img_x >= 1.0e9 || (double)g.N * g.Hp * g.Wp * 8.0 >= 2.0e9 * 4) return 1;
     const int hp2 = g.H / 2;
-    const int bpc = QNN_ENV_INT("QNN_U8_BPC", 4);           // workgroups per CU (experiment builds only)
-    const int blocks_cap = 256 * (bpc >= 1 && bpc <= 5 ? bpc : 4);
+    const bool fused = g.cout == 64 && w->wshift <= 6 && g.pool == 2 && e.out_store == QNN_STORE_I4 &&
+                       ((e.fn == QNN_FN_QUANTIZED_TANH && e.act_m <= 8.0f) || e.fn == QNN_FN_BINARY_TANH);
+    const bool full = !fused && g.pool == 1 && e.out_store != QNN_STORE_F32;
+    // persistent grid = what is resident: four workgroups per CU (three for the un-pooled packed form, launch bounds)
+    const int bpc = QNN_ENV_INT("QNN_U8_BPC", full ? (g.cout == 16 ? 6 : 3) : 4);   // (override: experiment builds only)
+    const int blocks_cap = 256 * (bpc >= 1 && bpc <= 8 ? bpc : 4);
     const long nwaves = (long)blocks_cap * 4;
     int best_rc = hp2, best_nch = 1;
     double best_cost = 1e300;

@@ -630,12 +630,16 @@ class ResidualFusedModel:
                 w.check()
 
     # ---- evaluation --------------------------------------------------------------
+    _in_forward = False
+
     def forward(self, x):
         if self.first_layer == "image" and isinstance(x, torch.Tensor) and x.dtype != torch.uint8:
             _abi.set_option("first_image", 1)      # only float32-input (3-channel) convs look at it
+            self._in_forward = True
             try:
                 return self._forward(x)
             finally:
+                self._in_forward = False
                 _abi.set_option("first_image", 0)
         return self._forward(x)
 
@@ -676,8 +680,17 @@ class ResidualFusedModel:
                 if src.dtype == torch.uint8:     # the images as bytes: typed QNN_STORE_U8 entry
                     xs = _abi.STORE_U8
 
+            # (bench.py re-issues this closure outside forward(): it carries the first-layer option itself)
+            opt = "first_image" if (self.first_layer == "image" and xs == _abi.STORE_F32 and C <= 4) else None
+
             def launch():
-                return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
+                if opt:
+                    _abi.set_option(opt, 1)
+                try:
+                    return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
+                finally:
+                    if opt and not self._in_forward:
+                        _abi.set_option(opt, 0)
 
             y, Ho, Wo = launch()
             if self.kernel_log is not None:
