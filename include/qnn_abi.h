@@ -69,6 +69,15 @@ extern "C" {
 #define QNN_STORE_I4  4
 #define QNN_STORE_I8  8
 #define QNN_STORE_U8  16  /* input only: unsigned image bytes, value = code / 255 */
+/* float32 input WITH A DECLARED DOMAIN (first layer of a network, 3x3 on 3 channels; any other layer treats them as
+ * QNN_STORE_F32).  The declaration selects the restricted-domain kernel for this call only -- no process-wide switch --
+ * and a value outside the domain raises the layer's domain flag (qnn_weights_check):
+ *   QNN_STORE_F32_IMAGE  the values are image bytes / 255 (utils/load_data.py:40): read as bytes, computed like QNN_STORE_U8
+ *   QNN_STORE_F32_UNIT   the values lie in [0, 1]: fixed point at 2^-23 (see "first_fixed" below)
+ * qnn_set_option("first_image" / "first_fixed", 1) makes the same declaration for every plain QNN_STORE_F32 call of the
+ * process. */
+#define QNN_STORE_F32_IMAGE 17
+#define QNN_STORE_F32_UNIT  18
 
 /* weight quantizers (what the layer applies to its latent fp32 kernel) */
 #define QNN_W_FLOAT    0   /* stock Conv2D / Dense: kernel used as is          */

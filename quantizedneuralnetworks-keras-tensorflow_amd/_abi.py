@@ -14,6 +14,7 @@ from . import _build
 
 QNN_OK = 0
 STORE_F32, STORE_BIN, STORE_T2, STORE_I4, STORE_I8, STORE_U8 = 0, 1, 2, 4, 8, 16
+STORE_F32_IMAGE, STORE_F32_UNIT = 17, 18      # float32 input with a declared domain (first layer; qnn_abi.h)
 W_FLOAT, W_BINARY, W_QUANT, W_TERNARY = 0, 1, 2, 3
 FN_NONE, FN_BINARY_TANH, FN_QUANTIZED_TANH, FN_TERNARY_TANH, FN_GRID = 0, 1, 2, 3, 4
 

@@ -15,6 +15,11 @@ std::atomic<int> g_option[QNN_OPT_COUNT] = {{1}, {-1}, {0}, {0}};    // strip ke
 
 int qnn_option(int which) { return g_option[which].load(std::memory_order_relaxed); }
 
+// domain declared for the float32 input of the conv call in flight on this thread: 0 none, 1 image bytes / 255, 2 [0, 1]
+namespace { thread_local int g_first_mode = 0; }
+void qnn_set_call_first_mode(int mode) { g_first_mode = mode; }
+int qnn_call_first_mode() { return g_first_mode; }
+
 extern "C" int qnn_set_option(const char* key, int value) {
     if (key && strcmp(key, "strip") == 0) {
         g_option[QNN_OPT_STRIP].store(value ? 1 : 0, std::memory_order_relaxed);

@@ -76,6 +76,8 @@ int qnn_conv_impl_pref();
 int qnn_head_prepare(qnn_weights* w, hipStream_t s);
 int qnn_try_launch_stem(const ConvGeom& g, const EpiArgs& e, const void* x, const float* wq, void* y, hipStream_t s);
 int qnn_option(int which);
+void qnn_set_call_first_mode(int mode);   // thread-local: domain declared for this call's float32 input (conv_forward)
+int qnn_call_first_mode();
 int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                                hipStream_t s);
 int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,

@@ -1181,6 +1181,16 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
                  int W, const qnn_epilogue_t* epi, void* y, void* stream, bool dense) {
     QNN_REQUIRE(w && x && y && epi, QNN_EINVAL, "conv_forward: null pointer");
     QNN_REQUIRE(N >= 0 && H > 0 && W > 0, QNN_EINVAL, "conv_forward: N=%d H=%d W=%d", N, H, W);
+    // float32 input with a declared domain (typed entry of this call, or the process-wide default): kept for the
+    // first-layer dispatch of this call on this thread
+    int first_mode = 0;
+    if (x_store == QNN_STORE_F32_IMAGE || x_store == QNN_STORE_F32_UNIT) {
+        first_mode = x_store == QNN_STORE_F32_IMAGE ? 1 : 2;
+        x_store = QNN_STORE_F32;
+    } else if (x_store == QNN_STORE_F32) {
+        first_mode = qnn_option(QNN_OPT_FIRST_IMAGE) ? 1 : qnn_option(QNN_OPT_FIRST_FIXED) ? 2 : 0;
+    }
+    qnn_set_call_first_mode(first_mode);
     int xshift = 0;
     if (x_store == QNN_STORE_F32) {
         // any float32 values; uses the float32 copy of the quantized kernel
@@ -1284,7 +1294,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
         return QNN_OK;
     }
     // opt-in: float32 images that are bytes / 255 on the byte kernels (qnn_first_u8.hip, F32IN; also the ResNet stem)
-    if (!launched && pref != 1 && !dense && x_store == QNN_STORE_F32 && qnn_option(QNN_OPT_FIRST_IMAGE) &&
+    if (!launched && pref != 1 && !dense && x_store == QNN_STORE_F32 && first_mode == 1 &&
         qnn_try_launch_first_u8(g, e, x, w, y, s, true) == 0) {
         launched = true;
         snprintf(name, sizeof(name), "mfma_i8_first_img255");

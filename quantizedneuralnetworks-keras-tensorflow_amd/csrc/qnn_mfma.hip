@@ -782,12 +782,12 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
         const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
         if (g.cout % pw != 0) return 1;
         // opt-in: float32 inputs that are image bytes / 255 on the uint8 entry's kernel (qnn_first_u8.hip, F32IN)
-        if (qnn_option(QNN_OPT_FIRST_IMAGE) && qnn_try_launch_first_u8(g, e, x, w, y, s, true) == 0) {
+        if (qnn_call_first_mode() == 1 && qnn_try_launch_first_u8(g, e, x, w, y, s, true) == 0) {
             snprintf(name, name_len, "mfma_i8_first_img255");
             return 0;
         }
         // opt-in fixed-point variant (qnn_first_fixed.hip): NOT the oracle's float32 chain, see its header
-        if (qnn_option(QNN_OPT_FIRST_FIXED) && qnn_try_launch_first_fixed(g, e, x, w, y, s) == 0) {
+        if (qnn_call_first_mode() == 2 && qnn_try_launch_first_fixed(g, e, x, w, y, s) == 0) {
             snprintf(name, name_len, "mfma_i8x3_first_fixed");
             return 0;
         }

@@ -116,14 +116,15 @@ class FusedModel:
     "image" and "fixed" have restricted domains; a value outside raises the layer's domain flag, which surfaces as
     QnnError from check_domain() (or from the next forward once the host has seen it) -- never silently."""
 
-    FIRST_LAYER_OPTION = {"exact": None, "fixed": "first_fixed", "image": "first_image"}
+    # how float32 images are declared to the C ABI: a typed entry per call, no process-wide switch is touched
+    FIRST_LAYER_STORE = {"exact": _abi.STORE_F32, "image": _abi.STORE_F32_IMAGE, "fixed": _abi.STORE_F32_UNIT}
 
     def __init__(self, spec, device="cuda", first_layer="exact", trick=None):
         """trick: None = the reference's lr-multiplier identity trick is the identity ("exact" mode, the default), or
         "nep50" / "legacy" = its OUTPUT side (binary_layers.py:175-176) is replayed in float32 behind every low-bit
         conv with the constants the reference forms under that numpy promotion rule (qnn_abi.h, trick_c / trick_s):
         reproduces the reference's rounding noise on 8-bit activation grids at the price of the VALU kernel family."""
-        if first_layer not in self.FIRST_LAYER_OPTION:
+        if first_layer not in self.FIRST_LAYER_STORE:
             raise ValueError("first_layer must be 'exact', 'image' or 'fixed', got %r" % (first_layer,))
         if trick not in (None, "nep50", "legacy"):
             raise ValueError("trick must be None, 'nep50' or 'legacy', got %r" % (trick,))
@@ -260,17 +261,17 @@ class FusedModel:
             return _abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
                               st["fn"], st["act_bits"], st["out_store"], out=out), H, W
         u8 = si == 0 and cur.dtype == torch.uint8
-        x_store = _abi.STORE_U8 if u8 else st["x_store"]
-        opt = self.FIRST_LAYER_OPTION[self.first_layer] if (si == 0 and not u8) else None
-        if opt:
-            _abi.set_option(opt, 1)
-        try:
-            return _abi.conv2d(st["w"], cur, x_store, st["x_bits"], N, H, W, st["inv"],
-                               st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"], out=out,
-                               trick=None if u8 else st["trick"])
-        finally:
-            if opt:
-                _abi.set_option(opt, 0)
+        x_store = _abi.STORE_U8 if u8 else self._x_store(si)
+        return _abi.conv2d(st["w"], cur, x_store, st["x_bits"], N, H, W, st["inv"],
+                           st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"], out=out,
+                           trick=None if u8 else st["trick"])
+
+    def _x_store(self, si):
+        """Input store of step si for float32 / packed inputs (the first step carries the declared image domain)."""
+        st = self.steps[si]
+        if si == 0 and st["x_store"] == _abi.STORE_F32:
+            return self.FIRST_LAYER_STORE[self.first_layer]
+        return st["x_store"]
 
     def bind(self, example):
         """A launch plan for batches shaped like `example`: every step bound to static intermediate tensors
@@ -293,7 +294,7 @@ class FusedModel:
                     cur = y
                     break
             out, H1, W1 = self.run_step(si, cur, N, H, W)
-            x_store = _abi.STORE_U8 if (u8 and si == 0) else st["x_store"]
+            x_store = _abi.STORE_U8 if (u8 and si == 0) else self._x_store(si)
             bound.append(_abi.BoundStep(st["kind"], st["w"], x_store, st["x_bits"], N, H, W, st["inv"], st["shift"],
                                         st["fn"], st["act_bits"], st["pool"], st["out_store"],
                                         None if si == 0 else cur, None if si == len(self.steps) - 1 else out,
@@ -630,20 +631,7 @@ class ResidualFusedModel:
                 w.check()
 
     # ---- evaluation --------------------------------------------------------------
-    _in_forward = False
-
     def forward(self, x):
-        if self.first_layer == "image" and isinstance(x, torch.Tensor) and x.dtype != torch.uint8:
-            _abi.set_option("first_image", 1)      # only float32-input (3-channel) convs look at it
-            self._in_forward = True
-            try:
-                return self._forward(x)
-            finally:
-                self._in_forward = False
-                _abi.set_option("first_image", 0)
-        return self._forward(x)
-
-    def _forward(self, x):
         x = (_abi.require_cuda_u8(x, "ResidualFusedModel.forward")
              if isinstance(x, torch.Tensor) and x.dtype == torch.uint8
              else _abi.require_cuda(x, "ResidualFusedModel.forward"))
@@ -680,17 +668,11 @@ class ResidualFusedModel:
                 if src.dtype == torch.uint8:     # the images as bytes: typed QNN_STORE_U8 entry
                     xs = _abi.STORE_U8
 
-            # (bench.py re-issues this closure outside forward(): it carries the first-layer option itself)
-            opt = "first_image" if (self.first_layer == "image" and xs == _abi.STORE_F32 and C <= 4) else None
+            if self.first_layer == "image" and xs == _abi.STORE_F32 and src is memo["input"]:
+                xs = _abi.STORE_F32_IMAGE        # the images: declared as bytes / 255 for this call (typed entry)
 
             def launch():
-                if opt:
-                    _abi.set_option(opt, 1)
-                try:
-                    return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
-                finally:
-                    if opt and not self._in_forward:
-                        _abi.set_option(opt, 0)
+                return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
 
             y, Ho, Wo = launch()
             if self.kernel_log is not None:
@@ -702,7 +684,9 @@ class ResidualFusedModel:
                 def nbytes(store, pixels, ch):
                     if store == _abi.STORE_U8:
                         return pixels * ch
-                    return pixels * ch * 4 if store == _abi.STORE_F32 else pixels * _abi.words(store, ch) * 4
+                    if store in (_abi.STORE_F32, _abi.STORE_F32_IMAGE, _abi.STORE_F32_UNIT):
+                        return pixels * ch * 4
+                    return pixels * _abi.words(store, ch) * 4
                 kh, kw = op["kernel"].shape[:2]
                 b = nbytes(xs, N * H * W, C) + nbytes(out_store, N * Ho * Wo, cout)
                 if res is not None:
@@ -711,7 +695,7 @@ class ResidualFusedModel:
                                          shape=(N, H, W, C, cout, kh, tuple(op.get("strides", (1, 1)))[0],
                                                 "res_" + ("none" if res is None else "packed" if isinstance(res, _Packed) else "f32")),
                                          bytes=b, macs=N * Ho * Wo * kh * kw * C * cout,
-                                         pipe="f32" if xs == _abi.STORE_F32 and "fixed" not in _abi.last_kernel() else "i8"))
+                                         pipe="f32" if _abi.last_kernel().startswith("mfma_f32") else "i8"))
             if out_store == _abi.STORE_F32:
                 return y
             return _Packed(y, out_store, bits, (N, Ho, Wo, cout))
@@ -961,18 +945,11 @@ class Pipelined:
         cur = torch.cuda.current_stream()
         for ln in lanes:
             ln["stream"].wait_stream(cur)
-        opt = m.FIRST_LAYER_OPTION[m.first_layer] if x.dtype != torch.uint8 else None
-        if opt:
-            _abi.set_option(opt, 1)
-        try:
-            xb, xs = x.data_ptr(), B * x.stride(0) * x.element_size()
-            yb, ys = outs.data_ptr(), B * outs.stride(0) * outs.element_size()
-            for i in range(nfull):
-                ln = lanes[i % len(lanes)]
-                ln["plan"](ln["stream"].cuda_stream, xb + i * xs, yb + i * ys)
-        finally:
-            if opt:
-                _abi.set_option(opt, 0)
+        xb, xs = x.data_ptr(), B * x.stride(0) * x.element_size()
+        yb, ys = outs.data_ptr(), B * outs.stride(0) * outs.element_size()
+        for i in range(nfull):
+            ln = lanes[i % len(lanes)]
+            ln["plan"](ln["stream"].cuda_stream, xb + i * xs, yb + i * ys)
         for ln in lanes:
             cur.wait_stream(ln["stream"])
         return outs
