@@ -131,6 +131,7 @@ class FusedModel:
         self.first_layer = first_layer
         self.device = torch.device(device)
         self.fuse_head = True                # conv group + Flatten + Dense in one launch where the library has the kernel
+        self._head_no = {}                   # (H, W) of inputs the library has no fused head kernel for
         self.steps = []
         self._keep = []
         groups = self._group(spec)
@@ -247,11 +248,14 @@ class FusedModel:
     def run_head(self, cur, N, H, W, out=None):
         """The last conv group and the classifier in one launch (qnn_conv2d_dense_forward); None if the library has no
         fused kernel for this geometry -- the caller then runs the two steps one after the other."""
-        if not self._head_candidate():
+        if not self._head_candidate() or self._head_no.get((H, W)):
             return None
         c, d = self.steps[-2], self.steps[-1]
-        return _abi.conv2d_dense(c["w"], d["w"], cur, c["x_store"], c["x_bits"], N, H, W, c["inv"], c["shift"], c["fn"],
-                                 c["act_bits"], d["inv"], d["shift"], out=out)
+        y = _abi.conv2d_dense(c["w"], d["w"], cur, c["x_store"], c["x_bits"], N, H, W, c["inv"], c["shift"], c["fn"],
+                              c["act_bits"], d["inv"], d["shift"], out=out)
+        if y is None:
+            self._head_no[(H, W)] = True     # no fused kernel for this geometry: do not ask again
+        return y
 
     def run_step(self, si, cur, N, H, W, out=None):
         """Launch step `si` on `cur` (the images for si = 0: float32 or uint8; else the previous step's output).
