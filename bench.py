@@ -373,7 +373,12 @@ def main_rank(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             os.environ["MASTER_PORT"] = str(free_port())       # single-rank rehearsal only
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl" and torch.cuda.device_count() > 0:
+            # bind the communicator to this rank's GPU up front (no "using the device under current context" guess)
+            dev_id = torch.device("cuda", local_rank % torch.cuda.device_count())
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev_id)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
