@@ -503,3 +503,31 @@ def test_resnet_and_deep_vgg_take_the_byte_kernels():
         m.kernel_log = []
         np.testing.assert_array_equal(host(m(dev(xin))), want)
         assert m.kernel_log[0] == tag, m.kernel_log[:2]
+
+
+@pytest.mark.parametrize("idx", [1, 2])
+def test_full_batch_4096_on_the_byte_entries(idx):
+    """BASELINE configs 2 / 3 at the benchmark's batch size through the uint8 and the image entries: identical bits
+    between the two, bit-exact against the specification on a slice spread over the batch, the domain check passes, and
+    the difference to the exact float32-input path is counted (not assumed)."""
+    cf = nets.baseline_config(idx)
+    spec = nets.build_spec(cf, nets.SEED_BASE + idx)
+    xu8 = nets.synthetic_images_u8(cf, 4096, 1234 + idx)
+    x = (xu8.astype(F32) / F32(255)).astype(F32)
+    m = engine.FusedModel(spec)
+    mi = engine.FusedModel(spec, first_layer="image")
+    y8 = host(m(dev(xu8)))
+    yi = host(mi(dev(x)))
+    mi.check_domain()
+    np.testing.assert_array_equal(y8, yi)
+    pick = np.arange(0, 4096, 97)
+    np.testing.assert_array_equal(y8[pick], O.run_spec_u8(spec, xu8[pick]))
+    ye = host(m(dev(x)))                                         # exact float32 FMA chain
+    rows = int((np.abs(y8 - ye).max(axis=1) > 0).sum())
+    print("\n[batch 4096, config %d] %d of 4096 logit rows differ between the byte entries and the exact float32 first "
+          "layer (max |d| %.3g); argmax agreement %.4f" % (idx + 1, rows, np.abs(y8 - ye).max(),
+                                                            (y8.argmax(1) == ye.argmax(1)).mean()))
+    assert rows <= 8 and (y8.argmax(1) == ye.argmax(1)).mean() >= 0.999
+    # the product call: same bits from predict() on numpy bytes
+    got = nets.Model(cf, spec).predict(xu8, batch_size=1024)
+    np.testing.assert_array_equal(got, y8)
