@@ -144,12 +144,15 @@ const char* qnn_last_error(void);
  * (XNOR+popcount / v_dot8 / v_dot4), 2 = prefer the int8 MFMA implicit GEMM.
  * Process-wide; results are bit-identical across families. */
 int         qnn_set_conv_impl(int impl);
-/* Kernel-selection switches for A/B measurements and tests; "strip" / "strip64" give bit-identical results under
+/* Kernel-selection switches for A/B measurements and tests; "strip" / "strip64" / "halo" give bit-identical results under
  * every setting, "first_fixed" does NOT (see below).
  *   "strip" (default 1): row-walking kernel for the 3x3 stride-1 int4 layers with 16 / 32 channels;
  *                        0 = the tile kernel (k_conv_mfma_small) takes them.
  *   "strip64" (default -1): the same kernel for 64-channel layers: 0 never (the LDS-weight kernel takes them), -1 / 1 always
  *                        (round 3: faster with and without a residual merge; pooled layers keep the LDS-weight kernel).
+ *   "halo" (default 1): pooled int4 layers with 64 input channels whose pooled map tiles into 8 x 2 or 4 x 4 rectangles
+ *                        stage each tile's receptive field once through LDS (k_conv_mfma_halo); 0 = the kernel that
+ *                        fetches the pixels per tap (k_conv_mfma_areg) takes them.
  *   "first_fixed" (default 0): 1 = float-input 3x3 layers with 3 channels, 64 filters of <= 4 bits and inputs in [0, 1]
  *                        run in fixed point (inputs rounded to 2^-23, exact int32 sums on the int8 matrix pipe, one
  *                        rounding): within 27 * 2^-24 + half an ulp of the REAL-number convolution, hence inside the

@@ -124,8 +124,8 @@ def set_conv_impl(impl):
 
 
 def set_option(key, value):
-    """Kernel-selection switch (qnn_set_option).  "strip" 0 / 1 and "strip64" -1 / 0 / 1: results are bit-identical under
-    every setting.  "first_fixed" 0 / 1: the opt-in fixed-point first layer (csrc/qnn_first_fixed.hip) -- within 1e-5 of
+    """Kernel-selection switch (qnn_set_option).  "strip" 0 / 1, "strip64" -1 / 0 / 1 and "halo" 0 / 1: results are bit-identical
+    under every setting.  "first_fixed" 0 / 1: the opt-in fixed-point first layer (csrc/qnn_first_fixed.hip) -- within 1e-5 of
     the ideal convolution but NOT the oracle's float32 chain; off by default."""
     check(load().qnn_set_option(key.encode(), int(value)), "qnn_set_option")
 

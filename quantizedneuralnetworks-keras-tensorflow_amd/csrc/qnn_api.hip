@@ -10,7 +10,7 @@ namespace {
 thread_local char g_error[512] = "";
 thread_local char g_kernel[64] = "";
 std::atomic<int> g_conv_impl{0};
-std::atomic<int> g_option[QNN_OPT_COUNT] = {{1}, {-1}, {0}, {0}};    // strip kernel on, Cin 64: auto
+std::atomic<int> g_option[QNN_OPT_COUNT] = {{1}, {-1}, {0}, {0}, {1}};    // strip kernel on, Cin 64: auto, halo kernel on
 }  // namespace
 
 int qnn_option(int which) { return g_option[which].load(std::memory_order_relaxed); }
@@ -31,6 +31,10 @@ extern "C" int qnn_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "first_fixed") == 0) {
         g_option[QNN_OPT_FIRST_FIXED].store(value ? 1 : 0, std::memory_order_relaxed);
+        return QNN_OK;
+    }
+    if (key && strcmp(key, "halo") == 0) {
+        g_option[QNN_OPT_HALO].store(value ? 1 : 0, std::memory_order_relaxed);
         return QNN_OK;
     }
     if (key && strcmp(key, "first_image") == 0) {

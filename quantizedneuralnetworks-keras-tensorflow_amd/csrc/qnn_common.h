@@ -82,7 +82,7 @@ int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* 
                                hipStream_t s);
 int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                             hipStream_t s, bool f32in);
-enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_FIRST_FIXED = 2, QNN_OPT_FIRST_IMAGE = 3, QNN_OPT_COUNT = 4 };
+enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_FIRST_FIXED = 2, QNN_OPT_FIRST_IMAGE = 3, QNN_OPT_HALO = 4, QNN_OPT_COUNT = 5 };
 
 // ---- division by a launch-constant via multiply-high (dividends < 2^31) ----------
 struct FastDiv {

@@ -1577,11 +1577,12 @@ extern "C" int qnn_conv2d_dense_forward(const qnn_weights_t* wc, const qnn_weigh
     }
     mg.x_bytes = (uint32_t)xb; mg.w_bytes = (uint32_t)wb; mg.ablate = 0;
     e.scale = e.scale * (1.0f / 256.0f);                    // both conv operands carry *16 (as qnn_try_launch_mfma)
-    if (qnn_launch_areg_head(mg, e, x, wc->d_mfma, wd, ed, y, (hipStream_t)stream) != 0) {
+    const char* kname = "";
+    if (qnn_launch_areg_head(mg, e, x, wc->d_mfma, wd, ed, y, (hipStream_t)stream, &kname) != 0) {
         qnn_set_error("qnn_conv2d_dense_forward: no fused kernel for this geometry");
         return QNN_EUNSUPPORTED;
     }
-    qnn_set_kernel_name("mfma_i4_areg64x64+dense");
+    qnn_set_kernel_name(kname);
     QNN_HIP(hipGetLastError());
     return QNN_OK;
 }

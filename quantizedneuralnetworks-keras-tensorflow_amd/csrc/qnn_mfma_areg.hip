@@ -753,6 +753,292 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_conv_mfma_halo (round 3): the pooled int4 layers of the CIFAR VGG (int4 in, Cin 64, 3x3 stride 1 SAME, 2x2 pool,
+// int4 out -- BinaryConv2D / QuantizedConv2D.call + BN + clip + MaxPooling2D, models/vgg.py:21-36) with the PIXEL
+// operand staged through LDS instead of fetched per tap.
+//
+// k_conv_mfma_areg above fetches and widens every input pixel once per tap: 9 x (2 loads, 2 address selects, 24
+// widening instructions) per 64-row tile, 40 % of the kernel's vector instructions, and the headline pipeline is bound
+// by the sum of its instruction streams.  Here a wave's 64 rows are a RECTANGLE of one image (TWP x
+// 16/TWP pooled pixels = 2 TWP x 32/TWP conv positions), so the tile's receptive field is a (2 TWP + 2) x (32/TWP + 2)
+// pixel region: it is fetched once (4 x 16-byte loads per lane, requested one tile ahead), widened once (code * 16, the
+// same byte order as the areg kernel, so the filter image is shared) and written to a WAVE-PRIVATE LDS region; the A
+// fragments of all nine taps are then ds_read_b128 with immediate offsets off four per-lane base addresses -- no
+// per-tap address arithmetic, no masks: pixels outside the image are zeros in the region (rows above / below fall out
+// of the image's buffer descriptor, the left / right halo lanes get an out-of-range offset).
+//
+// Region layout: two planes (k-block kk = channels [32 kk, 32 kk + 32) permuted as the areg operand), each
+// [row][pixel, padded to a multiple of 8 = 256 B][2 sixteen-byte slots]; slot = lane half lh XOR (row & 1).
+// ds_read_b128 is served in groups of 16 lanes of one half (MI355X_MICROARCH.md, LDS): the 16 pixels of a group are
+// 8 distinct columns modulo 8 on two rows of different parity (TWP 8), or 4 + 4 columns covering all residues on two
+// row pairs (TWP 4), for every tap -- 16 distinct slots of the 256-byte bank row, conflict-free.
+// Filters: LDS, shared by the workgroup's NW waves (as areg).  No barrier in the main loop: a wave's LDS operations
+// execute in order, and the region is its own.
+template <int TWP, int NW, bool HEAD>
+__global__ __launch_bounds__(NW * 64, 1) void k_conv_mfma_halo(MfmaGeom mg, EpiArgs e, const uint8_t* __restrict__ x,
+                                                               const uint8_t* __restrict__ wq8, void* __restrict__ y,
+                                                               int ntiles, FastDiv fd_tpi, int txn, FastDiv fd_txn,
+                                                               uint32_t img_bytes, HeadArgs hd) {
+    constexpr int THP = 16 / TWP;
+    constexpr int RW = 2 * TWP + 2, RH = 2 * THP + 2;     // region, pixels
+    constexpr int NCH = 2 * RW * RH;                       // 16-byte chunks of packed input (32 B per pixel)
+    constexpr int RWP = (RW + 7) & ~7;
+    constexpr int PITCH = RWP * 32, PLANE = RH * PITCH, REGION = 2 * PLANE;
+    constexpr int B_STEP = 64 * 64, FILT = 9 * B_STEP;
+    constexpr int HTAB = FILT + NW * REGION;
+    static_assert(NCH <= 256, "four load rounds per lane");
+    const ConvGeom& g = mg.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbase = blockIdx.y * 64;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
+
+    // ---- the slice's filters -> LDS (first four waves; the areg kernel's image and swizzle) ----
+    if (tid < 256) {
+        const int srow = tid >> 2, sch = tid & 3;
+        const int wv = (nbase + srow) * (9 * 64) + sch * 16;
+        uint4 wreg[9];
+#pragma unroll
+        for (int st = 0; st < 9; ++st)
+            wreg[st] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wv, st * 64, 0));
+#pragma unroll
+        for (int st = 0; st < 9; ++st)
+            *reinterpret_cast<uint4*>(smem + st * B_STEP + srow * 64 + ((sch ^ ((srow >> 2) & 3)) << 4)) = wreg[st];
+    }
+
+    // ---- epilogue constants (as k_conv_mfma_areg) ----
+    const bool binary = e.fn == QNN_FN_BINARY_TANH;
+    const float mfold = binary ? 1.0f : e.act_m;
+    LaneEpi ke[2];
+    FoldEpi fe[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        lane_epi_init<QNN_STORE_I4>(ke[b], e, nbase + b * 32 + li, li);
+        fe[b].nb = __fdiv_rn(ke[b].bias, e.scale);
+        fe[b].ninv = __fmul_rn(__fmul_rn(ke[b].inv, e.scale), mfold);
+        fe[b].nshift = __fmul_rn(ke[b].shift, mfold);
+    }
+    const bool all_pos = !__any((int)(ke[0].neg || ke[1].neg));
+    int hu = 0;
+    float hbias = 0.0f, hinv = 1.0f, hshift = 0.0f;
+    if constexpr (HEAD) {
+        for (int i = tid; i < 16 * 64 * 2; i += NW * 64) reinterpret_cast<uint32_t*>(smem + HTAB)[i] = hd.tab[i];
+        hu = ((lane & 1) ? 8 : 0) + ((lane & 2) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 8) ? 1 : 0);
+        if (hu < hd.units) {
+            hbias = hd.bias ? hd.bias[hu] : 0.0f;
+            hinv = hd.bn_inv ? hd.bn_inv[hu] : 1.0f;
+            hshift = hd.bn_inv ? hd.bn_shift[hu] : 0.0f;
+        }
+    }
+    // this lane's output word after the nibble transpose: local pooled pixel lane_row of the tile's TWP-wide rectangle
+    const int jl = li & 7;
+    const int lane_row = 2 * (jl & 3) + lh + 8 * (jl >> 2);
+    const int lane_off = ((lane_row / TWP) * g.Wp + (lane_row % TWP)) * e.ocw + ((nbase + li) >> 3);
+
+    // ---- staging lanes: chunk j = lane + 64 i is half (j & 1) of region pixel j >> 1 ----
+    const int regbase = FILT + wave * REGION;
+    int rel[4], wr_addr[4];
+    unsigned long long edgeL[4], edgeR[4];
+    bool wr_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane + 64 * i;
+        const int p = j >> 1, half = j & 1;
+        const int ry = p / RW, rx = p - ry * RW;
+        wr_ok[i] = j < NCH;
+        rel[i] = wr_ok[i] ? (ry * g.W + rx) * 32 + half * 16 : (int)0x80000000;
+        wr_addr[i] = regbase + ry * PITCH + rx * 32 + ((half ^ (ry & 1)) << 4);
+        edgeL[i] = __ballot(rx == 0);
+        edgeR[i] = __ballot(rx == RW - 1);
+    }
+    // ---- A fragments: rows mt * 32 + li = 4 * (pooled pixel) + (position in its 2x2 window) ----
+    int a_even[2], a_odd[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int q = 8 * mt + (li >> 2), sub = li & 3;
+        const int ry0 = 2 * (q / TWP) + (sub >> 1), rx0 = 2 * (q % TWP) + (sub & 1);
+        a_even[mt] = regbase + ry0 * PITCH + rx0 * 32 + ((lh ^ (ry0 & 1)) << 4);
+        a_odd[mt] = a_even[mt] ^ 16;
+    }
+    int fb_addr[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fb_addr[kk] = li * 64 + (((lh * 2 + kk) ^ ((li >> 2) & 3)) << 4);
+
+    const int t_stride = gridDim.x * NW;
+    int t = blockIdx.x * NW + wave;
+
+    uint4 L[4];
+    long pq_next = 0;
+    int n_next = 0;
+    auto fetch = [&](int tile) {                       // tile -> (image, tile row, tile column): wave-uniform
+        if (tile >= ntiles) return;
+        const int n = (int)qnn_div((uint32_t)tile, fd_tpi);
+        const int rest = tile - n * (int)fd_tpi.d;
+        const int ty = (int)qnn_div((uint32_t)rest, fd_txn);
+        const int tx = rest - ty * txn;
+        n_next = n;
+        pq_next = ((long)n * g.Hp + ty * THP) * g.Wp + tx * TWP;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(x) + (size_t)n * img_bytes, 0, (int)img_bytes, 0x00020000);
+        const int origin = ((2 * ty * THP - 1) * g.W + 2 * tx * TWP - 1) * 32;
+        const bool tl = tx == 0, tr = tx == txn - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned long long m = (tl ? edgeL[i] : 0ull) | (tr ? edgeR[i] : 0ull);
+            const bool out = __builtin_amdgcn_inverse_ballot_w64(m);
+            const int voff = out ? (int)0x80000000 : rel[i] + origin;
+            L[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff, 0, 0));
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 q = L[i];
+            const uint4 k0 = make_uint4((q.x << 4) & 0xF0F0F0F0u, q.x & 0xF0F0F0F0u, (q.y << 4) & 0xF0F0F0F0u, q.y & 0xF0F0F0F0u);
+            const uint4 k1 = make_uint4((q.z << 4) & 0xF0F0F0F0u, q.z & 0xF0F0F0F0u, (q.w << 4) & 0xF0F0F0F0u, q.w & 0xF0F0F0F0u);
+            if (i < 3 || wr_ok[i]) {
+                *reinterpret_cast<uint4*>(smem + wr_addr[i]) = k0;
+                *reinterpret_cast<uint4*>(smem + wr_addr[i] + PLANE) = k1;
+            }
+        }
+    };
+
+    v16i acc[2][2];
+    auto bn = [&](int v, const FoldEpi& f) {
+        return __fadd_rn(__fmul_rn(__fadd_rn((float)v, f.nb), f.ninv), f.nshift);
+    };
+    auto epilogue = [&](long pq0, int image) {
+        uint32_t* ytile = reinterpret_cast<uint32_t*>(y) + pq0 * e.ocw;
+        int dacc[16];
+        if constexpr (HEAD) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dacc[u] = 0;
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float tv[8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int i0 = acc[a][b][4 * g4], i1 = acc[a][b][4 * g4 + 1];
+                    const int i2 = acc[a][b][4 * g4 + 2], i3 = acc[a][b][4 * g4 + 3];
+                    const int mx = max(max(i0, i1), max(i2, i3));
+                    if (all_pos) {
+                        tv[a * 4 + g4] = bn(mx, fe[b]);
+                    } else {
+                        const int mn = min(min(i0, i1), min(i2, i3));
+                        tv[a * 4 + g4] = bn(ke[b].neg ? mn : mx, fe[b]);
+                    }
+                }
+            if constexpr (HEAD) {
+                const uint32_t Q = pack_scaled<4, 8>(tv, e.act_m, binary) ^ 0x88888888u;
+                const uint32_t* trow = reinterpret_cast<const uint32_t*>(smem + HTAB) + lane * 2 + b;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) dacc[u] = __builtin_amdgcn_sdot8((int)Q, (int)trow[u * 128], dacc[u], false);
+            } else {
+                const uint32_t P = pack_scaled<4, 8>(tv, e.act_m, binary);
+                ytile[lane_off + b * 4] = transpose_nib8(P, ke[0]) ^ 0x88888888u;
+            }
+        }
+        if constexpr (HEAD) {
+            int u;
+            const int tot = head_reduce16(dacc, lane, u);
+            if (lane < 16 && u < hd.units) {
+                float v = __fmul_rn((float)tot, hd.scale);
+                if (hd.bias) v = __fadd_rn(v, hbias);
+                if (hd.bn_inv) v = __fadd_rn(__fmul_rn(v, hinv), hshift);
+                hd.y[(long)image * hd.units + u] = v;
+            }
+        }
+    };
+
+    fetch(t);
+    __syncthreads();                                   // filters (and the classifier table) are in LDS
+    for (; t < ntiles; t += t_stride) {
+        const long pq0 = pq_next;
+        const int image = n_next;
+        stage();                                       // this tile's region (waits for its loads)
+        fetch(t + t_stride);                           // the next tile's loads fly under this tile's MFMAs
+        // 18 K-steps (tap, kk); the fragments of step s + 1 are requested before the MFMAs of step s are issued (two register
+        // sets), so a step's LDS latency lies under the previous step's 128 matrix-pipe cycles
+        v4i fa[2][2], fb[2][2];
+        auto frags = [&](int st, v4i (&A)[2], v4i (&B)[2]) {
+            const int tap = st >> 1, kk = st & 1;
+            const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                A[mt] = *reinterpret_cast<const v4i*>(smem + (dy == 1 ? a_odd[mt] : a_even[mt]) + kk * PLANE +
+                                                      dy * PITCH + dx * 32);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                B[b] = *reinterpret_cast<const v4i*>(smem + fb_addr[kk] + tap * B_STEP + b * 2048);
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) frags(st + 1, fa[(st + 1) & 1], fb[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (st == 0) {
+                        const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[st & 1][a], fb[st & 1][b], z, 0, 0, 0);
+                    } else {
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[st & 1][a], fb[st & 1][b], acc[a][b], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        epilogue(pq0, image);
+    }
+}
+
+template <int TWP, int NW, bool HEAD>
+void launch_halo_one(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, const HeadArgs& hd,
+                     hipStream_t s) {
+    const ConvGeom& g = mg.g;
+    constexpr int THP = 16 / TWP;
+    const int txn = g.Wp / TWP, tyn = g.Hp / THP;
+    const int tpi = txn * tyn;
+    const int ntiles = g.N * tpi;
+    constexpr int RW = 2 * TWP + 2, RH = 2 * THP + 2, RWP = (RW + 7) & ~7;
+    const size_t lds = (size_t)9 * 4096 + (size_t)NW * (2 * RH * RWP * 32) + (HEAD ? 16 * 64 * 2 * 4 : 0);
+    const int ny = g.cout / 64;
+    int gx = (ntiles + NW - 1) / NW;
+    const int cap = 256 / ny > 0 ? 256 / ny : 1;             // one resident workgroup per CU
+    if (gx > cap) gx = cap;
+    static const bool lds_ok = [] {
+        (void)hipFuncSetAttribute((const void*)k_conv_mfma_halo<TWP, NW, HEAD>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)lds_ok;
+    hipLaunchKernelGGL((k_conv_mfma_halo<TWP, NW, HEAD>), dim3((unsigned)gx, (unsigned)ny), dim3(NW * 64), lds, s, mg, e,
+                       (const uint8_t*)x, w, y, ntiles, qnn_fastdiv((uint32_t)tpi), txn, qnn_fastdiv((uint32_t)txn),
+                       (uint32_t)(g.H * g.W * 32), hd);
+}
+
+// 0 = launched.  The pooled map must tile into 8 x 2 or 4 x 4 rectangles; everything else stays on k_conv_mfma_areg.
+int halo_width(const MfmaGeom& mg, const EpiArgs& e) {
+    const ConvGeom& g = mg.g;
+    if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.pool != 2 || mg.kc != 1) return 0;
+    if (g.cout % 64 != 0 || e.out_store != QNN_STORE_I4 || e.res || (g.H & 1) || (g.W & 1)) return 0;
+    if ((long)g.N * g.Hp * g.Wp / 16 >= 2000000000L) return 0;
+    if (g.Wp % 8 == 0 && g.Hp % 2 == 0) return 8;
+    if (g.Wp % 4 == 0 && g.Hp % 4 == 0) return 4;
+    return 0;
+}
+
 template <int XS, int OUT, int KC>
 void launch_areg_pool(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y,
                       hipStream_t s) {
@@ -869,6 +1155,31 @@ int qnn_launch_areg(int x_store, int kc, const MfmaGeom& mg, const EpiArgs& e, c
     return kc == 1 ? launch_areg<QNN_STORE_I4, 1>(mg, e, x, w, y, s) : launch_areg<QNN_STORE_I4, 2>(mg, e, x, w, y, s);
 }
 
+// Waves per workgroup (they share one LDS copy of the filters): 8 = two per SIMD once there are tiles for every CU's eight
+// (measured on 4096 x 16^2 -> 8^2: 31.8 us against 33.8 us with 12, whose 5.33 tiles per wave leave a ragged last round),
+// 4 below that so that small batches still reach every CU.
+static int halo_waves(const MfmaGeom& mg, int tw) {
+    const long ntiles = (long)mg.g.N * (mg.g.Wp / tw) * (mg.g.Hp / (16 / tw));
+    static const int forced = QNN_ENV_INT("QNN_HALO_NW", 0);
+    if (forced == 4 || forced == 8) return forced;
+    return ntiles >= 256 * 8 ? 8 : 4;
+}
+
+int qnn_launch_halo(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s) {
+    const int tw = halo_width(mg, e);
+    if (tw == 0) return 1;
+    const int nw = halo_waves(mg, tw);
+    const HeadArgs none{};
+    if (tw == 8) {
+        if (nw == 8) launch_halo_one<8, 8, false>(mg, e, x, w, y, none, s);
+        else launch_halo_one<8, 4, false>(mg, e, x, w, y, none, s);
+    } else {
+        if (nw == 8) launch_halo_one<4, 8, false>(mg, e, x, w, y, none, s);
+        else launch_halo_one<4, 4, false>(mg, e, x, w, y, none, s);
+    }
+    return 0;
+}
+
 int qnn_launch_wres(int x_store, const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w,
                     void* y, hipStream_t s) {
     return x_store == QNN_STORE_I8 ? launch_wres<QNN_STORE_I8>(mg, e, x, w, y, s)
@@ -889,13 +1200,20 @@ int qnn_head_prepare(qnn_weights* w, hipStream_t s) {
 // 0 = launched.  Conv: int4 in, 3x3 stride 1 SAME, Cin 64 / 128, 64 filters, 2x2 pool, int4 codes out, 4 x 4 pooled map;
 // dense: the matching 1024 -> <= 16 head prepacked for int4.  `ed` is the dense layer's epilogue (float32 out, no fn).
 int qnn_launch_areg_head(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, const qnn_weights* wd,
-                         const EpiArgs& ed, float* y, hipStream_t s) {
+                         const EpiArgs& ed, float* y, hipStream_t s, const char** kname) {
     const ConvGeom& g = mg.g;
     if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.cout != 64 || g.pool != 2 || (mg.kc != 1 && mg.kc != 2)) return 1;
     if (g.Hp * g.Wp != 16 || e.out_store != QNN_STORE_I4 || e.res || !wd->d_head || wd->cin != 1024) return 1;
     HeadArgs hd;
     hd.tab = wd->d_head; hd.bias = ed.bias; hd.bn_inv = ed.bn_inv; hd.bn_shift = ed.bn_shift;
     hd.scale = ed.scale; hd.units = wd->cout; hd.y = y;
+    if (qnn_option(QNN_OPT_HALO) && halo_width(mg, e) == 4 && g.Wp == 4) {   // tile == image
+        if (halo_waves(mg, 4) == 8) launch_halo_one<4, 8, true>(mg, e, x, w, nullptr, hd, s);
+        else launch_halo_one<4, 4, true>(mg, e, x, w, nullptr, hd, s);
+        *kname = "mfma_i4_halo64x64+dense";
+        return 0;
+    }
+    *kname = "mfma_i4_areg64x64+dense";
     if (mg.kc == 1) launch_areg_head<1>(mg, e, x, w, hd, s);
     else launch_areg_head<2>(mg, e, x, w, hd, s);
     return 0;

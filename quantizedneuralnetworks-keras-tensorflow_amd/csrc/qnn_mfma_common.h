@@ -250,8 +250,9 @@ int qnn_launch_areg(int x_store, int kc, const MfmaGeom& mg, const EpiArgs& e, c
                     void* y, hipStream_t s);
 int qnn_launch_wres(int x_store, const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w,
                     void* y, hipStream_t s);
+int qnn_launch_halo(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s);
 int qnn_launch_areg_head(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, const qnn_weights* wd,
-                         const EpiArgs& ed, float* y, hipStream_t s);
+                         const EpiArgs& ed, float* y, hipStream_t s, const char** kname);
 int qnn_launch_small(int cin, const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w,
                      void* y, hipStream_t s);
 int qnn_launch_strip(int cin, const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w,
