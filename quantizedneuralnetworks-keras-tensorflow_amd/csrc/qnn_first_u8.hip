@@ -33,11 +33,15 @@ constexpr int kWaveLdsU = kRingU + 4;          // words per wave (a multiple of 
 // domain flag otherwise (qnn_weights_check), exactly like the fixed-point variant.  An accepted x is within 1.5e-7 of
 // k/255, so the result is within 27 * 1.5e-7 + one rounding of the real convolution of the floats: inside the 1e-5
 // contract for anything the check lets through, and the typed entry's exact result for real images.
+// Five instructions per element: t + 2^23 rounds t to an integer k (ties to even, as rint) and leaves k in the low bits of
+// the sum; the distance is taken to k CLAMPED to [0, 255], so an integer outside the byte range fails the same test as
+// a fraction does (NaN and infinities fail it too: every comparison with NaN is false).
 __device__ __forceinline__ uint32_t image_byte(float x, bool& bad) {
     const float t = __fmul_rn(x, 255.0f);
-    const float r = rintf(t);
-    bad |= !(fabsf(__fsub_rn(t, r)) <= 0x1p-15f && t >= -0.25f && t <= 255.25f);     // NaN / inf fail the first test
-    return (uint32_t)(int)fminf(fmaxf(r, 0.0f), 255.0f);
+    const float u = __fadd_rn(t, 8388608.0f);
+    const float r = __builtin_amdgcn_fmed3f(__fsub_rn(u, 8388608.0f), 0.0f, 255.0f);
+    bad |= !(fabsf(__fsub_rn(t, r)) <= 0x1p-15f);
+    return __float_as_uint(u);                      // low byte = k for every accepted x; only that byte is stored
 }
 
 // (QNN_STORE_I4, 2, BIN): the fused pipeline, quantized_tanh / binary_tanh codes;  (QNN_STORE_F32, 1, false): the layer

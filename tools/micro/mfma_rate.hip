@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256, 2) void k(int iters, int* out) {
             if (KIND == 1) acc16[m & 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc16[m & 3], 0, 0, 0);
             if (KIND == 2) accf4[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb, accf4[m], 0, 0, 0);
             if (KIND == 3) accf16[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, hb, accf16[m & 3], 0, 0, 0);
+            if (KIND == 4) acc4[m] = __builtin_amdgcn_mfma_i32_16x16x32_i8(((long)a.x << 32) | (unsigned)a.y, ((long)b.x << 32) | (unsigned)b.y, acc4[m], 0, 0, 0);   // the CDNA3 shape (K = 32)
         }
     }
     int s = 0;
@@ -57,6 +58,7 @@ int main() {
         run<1>("i8 32x32x32", 2.0 * 32 * 32 * 32, w);
         run<2>("bf16 16x16x32", 2.0 * 16 * 16 * 32, w);
         run<3>("bf16 32x32x16", 2.0 * 32 * 32 * 16, w);
+        run<4>("i8 16x16x32", 2.0 * 16 * 16 * 32, w);
     }
     return 0;
 }
