@@ -284,8 +284,20 @@ __global__ __launch_bounds__(256, (NBLK == 1 ? 6 : 3)) void k_conv_first_u8_full
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    const int cbase = blockIdx.y * (16 * NBLK);
+    // Workgroup -> (task stream xw, filter slice): the slices of one task stream sit on ONE XCD (workgroups are dealt to
+    // the eight XCDs round robin) and start together, so the 64-byte pieces of a stored pixel that different slices write
+    // meet in the same L2 instead of leaving four partial lines in four of them.  gridDim.y = slices, gridDim.x % 8 == 0
+    // (otherwise the plain mapping).
+    const int nsl = gridDim.y, bxw = gridDim.x;
+    const int bid = blockIdx.y * bxw + blockIdx.x;
+    int xw = blockIdx.x, slice = blockIdx.y;
+    if ((bxw & 7) == 0 && nsl > 1) {
+        const int xcd = bid & 7, j = bid >> 3;
+        slice = j % nsl;
+        xw = (j / nsl) * 8 + xcd;
+    }
+    const int wid = xw * 4 + wave, nw = bxw * 4;
+    const int cbase = slice * (16 * NBLK);
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem_u8) + wave * kWaveLdsU;
     uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
     uint4* tab = reinterpret_cast<uint4*>(smem_u8 + 4 * kWaveLdsU * 4);      // [filter block][lane][2]
