@@ -117,6 +117,26 @@ def test_binary_network_layers_on_int4_codes_use_the_halo_kernel_too():
     np.testing.assert_array_equal(got, _oracle_group(x, op, bn, BIN_ACT, 2))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_halo_kernel_random_tilings(seed):
+    """Random batch sizes, image sizes among those the kernel tiles, activation widths, bias on / off, weight kinds."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = [(4, 16), (8, 8), (8, 16), (16, 16), (12, 16), (16, 32), (8, 24), (16, 8), (20, 16), (24, 24)][seed]
+    N = int(rng.integers(1, 40))
+    kind = ["quantized", "binary"][seed % 2]
+    abits = 4 if kind == "quantized" else 1
+    _, x, op = _case("rnd%d" % seed, (N, H, W, 64), 64, kind=kind, nb=int(rng.integers(2, 5)), abits=abits, bias=bool(seed & 2))
+    if kind == "binary":
+        x = np.where(rng.random(x.shape) < 0.5, -1.0, 1.0).astype(F32)
+    bn = _rand_bn(rng, 64, 9 * 64 * (0.12 if kind == "quantized" else 1.0))
+    act = [Q(4), Q(3), Q(2), BIN_ACT][seed % 4]
+    in_act = Q(4) if kind == "quantized" else BIN_ACT
+    got, kern = _run_group(x, in_act, op, bn, act, 2, _abi.STORE_I4)
+    if kind == "quantized":
+        assert kern == "mfma_i4_halo64x64", kern
+    np.testing.assert_array_equal(got, _oracle_group(x, op, bn, act, 2))
+
+
 @pytest.mark.parametrize("units", [10, 16, 3])
 def test_fused_conv_classifier_on_the_halo_kernel(units):
     rng, x, op = _case("head%d" % units, (9, 8, 8, 64), 64)
