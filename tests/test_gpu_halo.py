@@ -21,15 +21,6 @@ pytestmark = pytest.mark.gpu
 F32 = np.float32
 
 
-@pytest.fixture
-def old_kernel():
-    _abi.set_option("halo", 0)
-    try:
-        yield
-    finally:
-        _abi.set_option("halo", 1)
-
-
 def _case(name, shape, cout, kind="quantized", nb=4, abits=4, bias=False):
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     m = 2 ** (abits - 1)
