@@ -769,10 +769,11 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
 // of the image's buffer descriptor, the left / right halo lanes get an out-of-range offset).
 //
 // Region layout: two planes (k-block kk = channels [32 kk, 32 kk + 32) permuted as the areg operand), each
-// [row][pixel, padded to a multiple of 8 = 256 B][2 sixteen-byte slots]; slot = lane half lh XOR (row & 1).
+// [row][pixel, rows padded to a multiple of 4 pixels = 128 B][2 sixteen-byte slots]; slot = lane half lh XOR (row & 1).
 // ds_read_b128 is served in groups of 16 lanes of one half (MI355X_MICROARCH.md, LDS): the 16 pixels of a group are
 // 8 distinct columns modulo 8 on two rows of different parity (TWP 8), or 4 + 4 columns covering all residues on two
-// row pairs (TWP 4), for every tap -- 16 distinct slots of the 256-byte bank row, conflict-free.
+// row pairs (TWP 4), for every tap; a row pitch of 128 (mod 256) bytes shifts the columns of every other row by four,
+// which permutes the residues -- 16 distinct slots of the 256-byte bank row either way, conflict-free.
 // Filters: LDS, shared by the workgroup's NW waves (as areg).  No barrier in the main loop: a wave's LDS operations
 // execute in order, and the region is its own.
 template <int TWP, int NW, bool HEAD>
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_mfma_halo(MfmaGeom mg, EpiA
     constexpr int THP = 16 / TWP;
     constexpr int RW = 2 * TWP + 2, RH = 2 * THP + 2;     // region, pixels
     constexpr int NCH = 2 * RW * RH;                       // 16-byte chunks of packed input (32 B per pixel)
-    constexpr int RWP = (RW + 7) & ~7;
+    constexpr int RWP = (RW + 3) & ~3;
     constexpr int PITCH = RWP * 32, PLANE = RH * PITCH, REGION = 2 * PLANE;
     constexpr int B_STEP = 64 * 64, FILT = 9 * B_STEP;
     constexpr int HTAB = FILT + NW * REGION;
@@ -1011,7 +1012,7 @@ void launch_halo_one(const MfmaGeom& mg, const EpiArgs& e, const void* x, const 
     const int txn = g.Wp / TWP, tyn = g.Hp / THP;
     const int tpi = txn * tyn;
     const int ntiles = g.N * tpi;
-    constexpr int RW = 2 * TWP + 2, RH = 2 * THP + 2, RWP = (RW + 7) & ~7;
+    constexpr int RW = 2 * TWP + 2, RH = 2 * THP + 2, RWP = (RW + 3) & ~3;
     const size_t lds = (size_t)9 * 4096 + (size_t)NW * (2 * RH * RWP * 32) + (HEAD ? 16 * 64 * 2 * 4 : 0);
     const int ny = g.cout / 64;
     int gx = (ntiles + NW - 1) / NW;
@@ -1156,7 +1157,7 @@ int qnn_launch_areg(int x_store, int kc, const MfmaGeom& mg, const EpiArgs& e, c
 }
 
 // Waves per workgroup (they share one LDS copy of the filters): 8 = two per SIMD once there are tiles for every CU's eight
-// (measured on 4096 x 16^2 -> 8^2: 31.8 us against 33.8 us with 12, whose 5.33 tiles per wave leave a ragged last round),
+// (measured on 4096 x 16^2 -> 8^2: one / two / three / four waves per SIMD = 42.9 / 32.3 / 33.8 / 35.3 us),
 // 4 below that so that small batches still reach every CU.
 static int halo_waves(const MfmaGeom& mg, int tw) {
     const long ntiles = (long)mg.g.N * (mg.g.Wp / tw) * (mg.g.Hp / (16 / tw));
