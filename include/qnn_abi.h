@@ -198,6 +198,9 @@ int qnn_unpack_f32(const void* x, float* y, size_t pixels, int channels,
  * models/resnet.py:134 behind the last activation.  Exact window sums of the codes, one float32 division. */
 int qnn_avgpool_packed_f32(const void* x, int store, int bits, int N, int H, int W, int C, int size,
                            float* y, void* stream);
+/* softmax over the last axis of a (rows, cols) float32 matrix, evaluated in float64 and rounded once: the classifier's
+ * activation='softmax' (models/resnet.py:137).  x == y allowed. */
+int qnn_softmax_f32(const float* x, float* y, size_t rows, int cols, void* stream);
 
 /* ---- weights -------------------------------------------------------------- */
 /*

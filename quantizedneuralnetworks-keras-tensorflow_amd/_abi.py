@@ -22,7 +22,7 @@ EXPORTS = [
     "qnn_version", "qnn_last_error", "qnn_last_kernel", "qnn_set_conv_impl", "qnn_set_option",
     "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
     "qnn_ternary_abs_sum_f32", "qnn_ternary_apply_f32",
-    "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32", "qnn_avgpool_packed_f32",
+    "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32", "qnn_avgpool_packed_f32", "qnn_softmax_f32",
     "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant", "qnn_weights_check",
     "qnn_conv2d_forward", "qnn_dense_forward", "qnn_conv2d_forward_f32in", "qnn_conv2d_workspace_bytes",
     "qnn_conv2d_dense_forward",
@@ -85,6 +85,7 @@ def load():
     lib.qnn_pack_f32.argtypes = [vp, vp, sz, ci, ci, ci, ci, vp]
     lib.qnn_unpack_f32.argtypes = [vp, vp, sz, ci, ci, ci, vp]
     lib.qnn_avgpool_packed_f32.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+    lib.qnn_softmax_f32.argtypes = [vp, vp, ctypes.c_size_t, ci, vp]
     lib.qnn_prepack_weights.argtypes = [ci, ci, fl, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp,
                                         ctypes.POINTER(vp)]
     lib.qnn_free_weights.argtypes = [vp]
@@ -216,6 +217,16 @@ def avgpool_packed(p, store, bits, N, H, W, C, size):
     check(load().qnn_avgpool_packed_f32(ptr(p), store, bits, N, H, W, C, size, ptr(out), stream_ptr()),
           "qnn_avgpool_packed_f32")
     return out
+
+
+def softmax(x, out=None):
+    """qnn_softmax_f32 over the last axis (float64 inside, one rounding): Dense(..., activation='softmax')."""
+    x = require_cuda(x, "softmax input").contiguous()
+    assert x.dtype == torch.float32
+    y = out if out is not None else torch.empty_like(x)
+    cols = x.shape[-1]
+    check(load().qnn_softmax_f32(ptr(x), ptr(y), x.numel() // cols, cols, stream_ptr()), "qnn_softmax_f32")
+    return y
 
 
 class Weights:

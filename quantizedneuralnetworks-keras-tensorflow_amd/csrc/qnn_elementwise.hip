@@ -289,6 +289,69 @@ __global__ __launch_bounds__(kBlock) void k_avgpool_packed(const uint32_t* __res
     }
 }
 
+// The same average for int4 codes with whole pixels per lane group: a wave owns one (output pixel, 64-channel block); lane
+// = (pixel slot p = lane >> 3, word j = lane & 7), so one load instruction fetches eight whole 32-byte pixel blocks (the
+// generic kernel above reads 4 bytes per lane 32 bytes apart and needs size^2 loads per lane: 19.5 us for the 8 x 8 pool
+// behind the ImageNet ResNet, models/resnet.py:131); eight integer partial sums per lane, three shuffles, the same one
+// rounding.  C % 64 == 0.
+__global__ __launch_bounds__(256) void k_avgpool_i4_wave(const uint32_t* __restrict__ x, float* __restrict__ y, long nout,
+                                                         int Ho, int Wo, int W, int H, int C, int cw, int size, float inv_m) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane >> 3, j = lane & 7;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int cblocks = C / 64;
+    if (wave >= nout * cblocks) return;
+    const int cb = (int)(wave % cblocks);
+    const long q = wave / cblocks;
+    const int ox = (int)(q % Wo), oy = (int)((q / Wo) % Ho);
+    const long n = q / ((long)Wo * Ho);
+    const int area = size * size;
+    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = p; k < area; k += 8) {
+        const int dy = k / size, dx = k - dy * size;
+        const uint32_t word = x[((n * H + (long)oy * size + dy) * W + (long)ox * size + dx) * cw + cb * 8 + j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += (int)(word << (28 - 4 * i)) >> 28;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        acc[i] += __shfl_xor(acc[i], 8);
+        acc[i] += __shfl_xor(acc[i], 16);
+        acc[i] += __shfl_xor(acc[i], 32);
+    }
+    if (p == 0) {
+        float* yo = y + q * C + cb * 64 + j * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yo[i] = __fdiv_rn(__fmul_rn((float)acc[i], inv_m), (float)area);
+    }
+}
+
+// softmax over the last axis in float64 (max-shifted), one 256-thread workgroup per row (a classifier has few rows and
+// ~1000 columns: one wave per row left most of the chip idle behind 3 x 16 serial float64 exponentials per lane):
+// the classifier activation of models/resnet.py:137.
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ x, float* __restrict__ y, int cols) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (size_t)blockIdx.x * cols;
+    float* yr = y + (size_t)blockIdx.x * cols;
+    double mx = -__builtin_huge_val();
+    for (int c = tid; c < cols; c += 256) mx = fmax(mx, (double)xr[c]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    double sum = 0.0;
+    for (int c = tid; c < cols; c += 256) sum += exp((double)xr[c] - mx);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int c = tid; c < cols; c += 256) yr[c] = (float)(exp((double)xr[c] - mx) / sum);
+}
+
 }  // namespace
 
 extern "C" int qnn_avgpool_packed_f32(const void* x, int store, int bits, int N, int H, int W, int C, int size,
@@ -306,6 +369,13 @@ extern "C" int qnn_avgpool_packed_f32(const void* x, int store, int bits, int N,
     if (blocks > 65535u) blocks = 65535u;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t* xu = (const uint32_t*)x;
+    if (store == QNN_STORE_I4 && C % 64 == 0 && size * size >= 8) {
+        const long nout = (long)N * (H / size) * (W / size), nwaves = nout * (C / 64);
+        hipLaunchKernelGGL(k_avgpool_i4_wave, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, xu, y, nout, H / size, W / size,
+                           W, H, C, cw, size, inv_m);
+        QNN_HIP(hipGetLastError());
+        return QNN_OK;
+    }
     if (store == QNN_STORE_BIN)
         hipLaunchKernelGGL(k_avgpool_packed<QNN_STORE_BIN>, dim3((unsigned)blocks), dim3(kBlock), 0, s, xu, y, N, H, W, C, cw, size, inv_m);
     else if (store == QNN_STORE_I4)
@@ -454,6 +524,16 @@ extern "C" int qnn_unpack_f32(const void* x, float* y, size_t pixels, int channe
         qnn_set_error("qnn_unpack_f32: store=%d is not a packed kind", store);
         return QNN_EINVAL;
     }
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}
+
+extern "C" int qnn_softmax_f32(const float* x, float* y, size_t rows, int cols, void* stream) {
+    QNN_REQUIRE(cols > 0, QNN_EINVAL, "qnn_softmax_f32: cols=%d", cols);
+    if (rows == 0) return QNN_OK;
+    QNN_REQUIRE(x && y, QNN_EINVAL, "qnn_softmax_f32: null pointer");
+    QNN_REQUIRE(rows < 2000000000ul, QNN_EUNSUPPORTED, "qnn_softmax_f32: too many rows for one launch");
+    hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, y, cols);
     QNN_HIP(hipGetLastError());
     return QNN_OK;
 }

@@ -329,7 +329,7 @@ class FusedModel:
             if log is not None:
                 log.append(_abi.last_kernel())
             if self.steps[si]["softmax"]:
-                cur = torch.softmax(cur, dim=-1)
+                cur = _abi.softmax(cur)
         return cur
 
     def forward(self, x):
@@ -514,7 +514,7 @@ class GraphModel:
             elif kind == "scale":
                 y = self._plain(src) * F32(op["value"])
             elif kind == "softmax":
-                y = torch.softmax(self._plain(src).double(), dim=-1).float()
+                y = _abi.softmax(self._plain(src))
             else:
                 raise ValueError(kind)
             env[name] = y
@@ -834,7 +834,7 @@ class ResidualFusedModel:
                 p_ = op["pad"]
                 out = torch.nn.functional.pad(f32(self.srcs[i][0]), (0, 0, p_, p_, p_, p_))
             elif kind == "softmax":
-                out = torch.softmax(f32(self.srcs[i][0]).double(), dim=-1).float()
+                out = _abi.softmax(f32(self.srcs[i][0]))
             else:
                 raise ValueError(kind)
             memo[name] = out
@@ -1103,7 +1103,7 @@ class LayerModel:
                 elif kind == "scale":
                     y = src * F32(op["value"])
                 elif kind == "softmax":
-                    y = torch.softmax(src.double(), dim=-1).float()
+                    y = _abi.softmax(src)
                 else:
                     raise ValueError(kind)
             env[name] = y

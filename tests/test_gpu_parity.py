@@ -721,7 +721,8 @@ def test_config5_imagenet224_resnet_nres10_at_spec():
 
 @pytest.mark.parametrize("store,bits,shape,size", [(_abi.STORE_I4, 4, (3, 56, 56, 64), 8), (_abi.STORE_I4, 2, (2, 9, 10, 24), 3),
                                                    (_abi.STORE_I8, 8, (2, 16, 16, 12), 8), (_abi.STORE_BIN, 1, (2, 8, 8, 64), 8),
-                                                   (_abi.STORE_I4, 4, (1, 8, 8, 16), 8)])
+                                                   (_abi.STORE_I4, 4, (1, 8, 8, 16), 8), (_abi.STORE_I4, 3, (5, 12, 20, 128), 4),
+                                                   (_abi.STORE_I4, 4, (2, 9, 9, 64), 3)])
 def test_average_pool_on_packed_codes(store, bits, shape, size):
     """AveragePooling2D behind the last activation (resnet.py:134) reads the packed codes: exact window sums."""
     rng = np.random.default_rng(bits + shape[1])

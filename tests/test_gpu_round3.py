@@ -237,3 +237,20 @@ def test_fused_classifier_only_where_the_kernel_exists():
         assert not any("+dense" in k for k in m3.kernel_log)
     finally:
         _abi.set_conv_impl(_abi.IMPL_AUTO)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 1000), (5, 10), (1, 1), (300, 7), (0, 10)])
+def test_softmax_entry_matches_the_float64_definition(rows, cols):
+    """qnn_softmax_f32 (the classifier's activation='softmax', models/resnet.py:137): float64 inside, one rounding -- equal to
+    the oracle's definition to the last float32 bit except where exp differs by an ulp (atol 1e-7 on probabilities)."""
+    rng = np.random.default_rng(rows * 31 + cols)
+    x = (rng.standard_normal((rows, cols)) * 6).astype(np.float32)
+    if rows:
+        x[0, 0] = 80.0                                  # float32 exp would overflow without the max shift
+    got = host(_abi.softmax(dev(x)))
+    assert got.shape == x.shape
+    if rows:
+        np.testing.assert_allclose(got, O.softmax(x), rtol=0, atol=1e-7)
+        np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-6)
+        want_t = torch.softmax(dev(x).double(), dim=-1).float()
+        np.testing.assert_allclose(got, host(want_t), rtol=0, atol=1e-7)
