@@ -715,12 +715,11 @@ __device__ __forceinline__ void qnn_collect_masks(const float (&v)[U], float thr
 // Validity of the 3x3 taps is wave-uniform: the row class (top / middle / bottom) is fixed along a row and the column
 // class only differs for the first and last pixel, so each class gets its own straight-line code (compile-time tap
 // masks): nine LDS broadcast reads issued up front, no branches.
-template <int CW>
+template <int CW, bool HAS_BN>
 __device__ __forceinline__ void xnor_f32_rows(const ConvGeom& g, const EpiArgs& e, const uint2* tile,
                                               const uint32_t (&wreg)[9 * CW], float bias, float inv, float shift,
                                               int n, int r0, int rows_out, int wave, int c, float* __restrict__ y) {
     constexpr int PAIRS = CW / 2;
-    const bool has_bn = e.bn_inv != nullptr;
     const float kf_cin = (float)g.cin;
     auto pixel = [&](auto rm_c, auto cm_c, const uint2* rowbase, float* yrow, int ox) {
         constexpr int RM = decltype(rm_c)::value;      // bit dy set = row dy of the window is outside
@@ -753,7 +752,8 @@ __device__ __forceinline__ void xnor_f32_rows(const ConvGeom& g, const EpiArgs& 
         // K - 2*acc: both integers < 2^24, so the float FMA below is exact
         float v = fmaf((float)acc, -2.0f, (float)NVALID * kf_cin);
         v = __fadd_rn(v, bias);
-        if (has_bn) v = __fadd_rn(__fmul_rn(v, inv), shift);
+        // (compile time: as a run-time flag the BN multiply and add were executed for every value and then deselected)
+        if constexpr (HAS_BN) v = __fadd_rn(__fmul_rn(v, inv), shift);
         if (e.fn == QNN_FN_BINARY_TANH) v = qnn_binary_tanh(v);
         else if (e.fn == QNN_FN_QUANTIZED_TANH) v = qnn_quantized_tanh(v, e.act_m);
         // written once, read by a later kernel at the earliest: the non-temporal hint keeps the
@@ -823,7 +823,8 @@ __global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e,
     const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
     const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
     __syncthreads();
-    xnor_f32_rows<CW>(g, e, tile, wreg, bias, inv, shift, n, r0, rows_out, wave, c, y);
+    if (e.bn_inv) xnor_f32_rows<CW, true>(g, e, tile, wreg, bias, inv, shift, n, r0, rows_out, wave, c, y);
+    else xnor_f32_rows<CW, false>(g, e, tile, wreg, bias, inv, shift, n, r0, rows_out, wave, c, y);
 }
 
 // (Measured dead end, round 2: the same layer as a PERSISTENT double-buffered pipeline -- workgroups walking strips, the
