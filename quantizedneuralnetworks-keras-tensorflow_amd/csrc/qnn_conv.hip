@@ -781,11 +781,8 @@ __device__ __forceinline__ void xnor_f32_rows(const ConvGeom& g, const EpiArgs& 
     }
 }
 
-#ifndef QNN_XNOR_F32_WGS
-#define QNN_XNOR_F32_WGS 8      // Cin 64: eight workgroups (61 VGPRs) per CU; measured within 1 % of the unconstrained 84-VGPR build
-#endif
 template <int CW>   // packed words per pixel (cin / 32), even
-__global__ __launch_bounds__(kBlock, (CW == 2 ? QNN_XNOR_F32_WGS : 1)) void k_conv_xnor_f32(ConvGeom g, EpiArgs e, int in_fn, int TR,
+__global__ __launch_bounds__(kBlock) void k_conv_xnor_f32(ConvGeom g, EpiArgs e, int in_fn, int TR,
                                                           int strips, const float* __restrict__ x,
                                                           const uint32_t* __restrict__ wp,
                                                           float* __restrict__ y) {
@@ -816,24 +813,16 @@ __global__ __launch_bounds__(kBlock, (CW == 2 ? QNN_XNOR_F32_WGS : 1)) void k_co
         qnn_collect_masks<0, U>(v, thr, mlo, mhi);
         if (lane < U && gi + lane < groups) tdst[gi + lane] = make_uint2(mlo, mhi);
     }
-    // ---- this lane's filter, through LDS: the workgroup copies the slice's 64 filters with coalesced loads (odd row pitch),
-    // each lane then reads its 9 * CW words.  (Read straight from global memory, every one of the 9 * CW loads of a wave
-    // touched 36 cache lines -- lanes 72 * CW / 2 bytes apart -- 2 % of the layer time on the 8 x 8 and 16 x 16
-    // CIFAR layers, A/B on one box.) ----
-    constexpr int WROW = 9 * CW + 1;
-    uint32_t* wfil = reinterpret_cast<uint32_t*>(tile + (size_t)(TR + 2) * g.W * PAIRS);
-    for (int i = threadIdx.x; i < 64 * 9 * CW; i += kBlock) {
-        const int fc = i / (9 * CW);
-        wfil[fc * WROW + (i - fc * (9 * CW))] = wp[(size_t)cbase * (9 * CW) + i];
-    }
+    // ---- this lane's filter ----
+    uint32_t wreg[9 * CW];
+    const uint32_t* wsrc = wp + (size_t)(cbase + lane) * (9 * CW);
+#pragma unroll
+    for (int k = 0; k < 9 * CW; ++k) wreg[k] = wsrc[k];
     const int c = cbase + lane;
     const float bias = e.bias ? e.bias[c] : 0.0f;
     const float inv = e.bn_inv ? e.bn_inv[c] : 1.0f;
     const float shift = e.bn_inv ? e.bn_shift[c] : 0.0f;
     __syncthreads();
-    uint32_t wreg[9 * CW];
-#pragma unroll
-    for (int k = 0; k < 9 * CW; ++k) wreg[k] = wfil[lane * WROW + k];
     if (e.bn_inv) xnor_f32_rows<CW, true>(g, e, tile, wreg, bias, inv, shift, n, r0, rows_out, wave, c, y);
     else xnor_f32_rows<CW, false>(g, e, tile, wreg, bias, inv, shift, n, r0, rows_out, wave, c, y);
 }
@@ -1039,7 +1028,7 @@ int try_launch_xnor_f32(const ConvGeom& g, const EpiArgs& e, int in_fn, const fl
     if (tr_env > 0 && tr_env < TR) TR = tr_env;
     else if (tr_env == 0 && TR > 8 && (TR % 8) == 0) TR = 8;    // measured: more, smaller items overlap load and compute better
     const int strips = (g.H + TR - 1) / TR;
-    const size_t lds = (size_t)(TR + 2) * g.W * cw * 4 + (size_t)64 * (9 * cw + 1) * 4;     // rows + the slice's filters
+    const size_t lds = (size_t)(TR + 2) * g.W * cw * 4;
     snprintf(name, name_len, "xnor_f32_cw%d", cw);
     const dim3 grid((unsigned)(g.N * strips), (unsigned)(g.cout / 64)), block(kBlock);
     if (cw == 2) hipLaunchKernelGGL(k_conv_xnor_f32<2>, grid, block, lds, s, g, e, in_fn, TR, strips, x, w->d_packed, (float*)y);
