@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""A/B of the 1-bit XNOR layer op (float32 NHWC in and out, CIFAR B0 16x16 and C0 8x8 at batch 4096) between library
+builds on ONE box:  QNN_LIB=<variant .so> python tools/ab_xnor.py  -- alternate the builds several times in one gpurun call
+(boxes differ by up to 10 % on this VALU-bound kernel).  Prints the fraction of the 8 TB/s HBM roof on the M0 bytes."""
 import importlib, os, sys, json
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
