@@ -897,6 +897,8 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     const bool areg_fit = g.kh == 3 && g.kw == 3 && mg.kc <= 2 && rows_ < 2000000000L;
     const bool areg = areg_env == 0 ? false : areg_env == 1 ? areg_fit : (areg_fit && g.cout == 64 && !tile_env && wres_env < 0);
     if (e.res && !(areg && g.pool == 1)) return 1;          // the other MFMA kernels have no residual epilogue
+    // pooled int4 layers whose pooled map tiles into 8 x 2 / 4 x 4 rectangles: receptive field staged once through LDS
+    // (k_conv_mfma_halo, qnn_mfma_areg.hip; qnn_set_option("halo", 0) keeps them on the per-tap kernel below)
     if (areg && x_store == QNN_STORE_I4 && qnn_option(QNN_OPT_HALO) &&
         qnn_launch_halo(mg, e2, x, w->d_mfma, y, s) == 0) {
         snprintf(name, name_len, "mfma_i4_halo64x64");
