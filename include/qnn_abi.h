@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define QNN_ABI_VERSION 3
+#define QNN_ABI_VERSION 4
 
 /* status codes */
 #define QNN_OK            0
@@ -93,6 +93,7 @@ extern "C" {
 #define QNN_FN_GRID            4   /* input is already on the grid: encode only  */
 
 typedef struct qnn_weights qnn_weights_t;   /* opaque prepacked layer weights */
+typedef struct qnn_fold qnn_fold_t;         /* opaque: one layer's epilogue folded over its accumulator domain (below) */
 
 /*
  * Epilogue fused behind the contraction.  Steps, in the reference's op order:
@@ -135,6 +136,7 @@ typedef struct qnn_epilogue {
     float post_scale;        /* multiplier after the add (0.5 in resnet.py:128; 1 = none) */
     float trick_c;           /* output-side identity trick: 1 - 1/klm (ignored when trick_s == 0) */
     float trick_s;           /* klm, or 0 = the trick is the identity (default)                    */
+    const qnn_fold_t* fold;  /* qnn_fold_prepare() of exactly this layer + epilogue, or NULL (ABI 4)  */
 } qnn_epilogue_t;
 
 /* ---- library ------------------------------------------------------------ */
@@ -235,6 +237,53 @@ int qnn_weights_dequant(const qnn_weights_t* w, float* kernel_hwio, void* stream
  * Layers whose kernels accept every input never raise it: the call is then just the stream synchronisation.
  */
 int qnn_weights_check(const qnn_weights_t* w, void* stream);
+
+/* ---- the epilogue as integer thresholds ------------------------------------- */
+/*
+ * Everything the reference computes behind a low-bit convolution -- K.bias_add, the inference BatchNormalization,
+ * the residual merge and quantized_tanh (models/vgg.py:16-17,23; models/resnet.py:59-63,127-129) -- is, per output
+ * channel, a MONOTONE STEP FUNCTION of the integer accumulator (and of the shortcut code): at most 2^act_bits - 1
+ * thresholds.  The accumulator domain of a layer is finite and known from its weights:
+ *     acc in [ sum_k min(w_k a_min, w_k a_max),  sum_k max(w_k a_min, w_k a_max) ],   a = the input codes' range.
+ * qnn_fold_prepare evaluates the reference-order float32 chain (exactly the arithmetic of the un-folded kernels) on
+ * EVERY point of that domain (x every shortcut code), on the GPU, and looks per channel for two constants -- a float32
+ * slope A[c] and an integer offset beta[c] in accumulator units / 256 -- such that
+ *     code = sat16( round( (acc*256 + beta[c]) * A[c] * 32767 ) ) >> 12                    (no shortcut)
+ *     code = sat16( 2 * sat16( round((acc*256 + beta[c]) * A[c] * 32767) + (sc + 8) * 1024 ) ) >> 12     (shortcut code sc)
+ * (v_cvt_f32_i32, v_mul_f32, v_cvt_pknorm_i16_f32, v_pk_add_i16 clamp: 3 to 5 vector instructions per value instead
+ * of 6 to 10) reproduces the chain's code on every point.  The offset costs nothing: it is the initial value of the
+ * MFMA accumulator.  A fold is accepted only if the exhaustive comparison finds no differing point; otherwise the
+ * handle is marked "not folded" and the kernels keep evaluating the float32 chain -- results are bit-identical either
+ * way, which is what the sweep proves.
+ *
+ * Supported today: weights prepacked for QNN_STORE_I4 with an int8 matrix-pipe image (3x3 / 1x1 convolutions),
+ * x_store = QNN_STORE_I4, fn = QNN_FN_QUANTIZED_TANH with act_bits = 4, out_store = QNN_STORE_I4, no output-side
+ * trick; a shortcut must be QNN_STORE_I4 codes of 4 bits with post_scale = 0.5.  Anything else: QNN_EUNSUPPORTED.
+ * The call synchronises `stream` (it is a set-up call, like qnn_prepack_weights).  epi->res / epi->fold are ignored;
+ * whether epi->res is NULL decides between the two forms.  The handle records the layer and the epilogue constants it
+ * was built for; qnn_conv2d_forward rejects it (QNN_EINVAL) for any other combination.  The BN constant arrays must
+ * not change while the handle is in use.
+ */
+int qnn_fold_prepare(const qnn_weights_t* w, int x_store, int x_bits, const qnn_epilogue_t* epi, void* stream,
+                     qnn_fold_t** out);
+int qnn_fold_free(qnn_fold_t* f);
+typedef struct qnn_fold_info {
+    int32_t channels;        /* cout                                                                  */
+    int32_t folded;          /* channels for which (A, beta) reproduce the chain on the whole domain  */
+    int32_t usable;          /* 1 if folded == channels: the kernels use the fold                      */
+    int32_t shortcut_codes;  /* 16 with a shortcut, else 1                                            */
+    int64_t points;          /* (accumulator, shortcut) points compared, summed over the channels      */
+    int32_t acc_lo, acc_hi;  /* union of the channels' accumulator domains (true integer units)        */
+} qnn_fold_info_t;
+int qnn_fold_info(const qnn_fold_t* f, qnn_fold_info_t* info);
+/* DEVICE copies of A[cout] (float32) and beta[cout] (int32) -- tests and diagnostics */
+int qnn_fold_constants(const qnn_fold_t* f, float* A, int32_t* beta, void* stream);
+/* Evaluate the FOLDED epilogue (the very device function the kernels inline) for channel `c` on n accumulator values
+ * acc[i] (true integer units, DEVICE int32) and, with a shortcut, shortcut codes sc[i] (DEVICE int32, else NULL):
+ * codes[i] (DEVICE int32) = the 4-bit output code.  Lets a test sweep the whole domain against an independent
+ * restatement of the reference chain. */
+int qnn_fold_eval(const qnn_fold_t* f, int c, const int32_t* acc, const int32_t* sc, int32_t* codes, size_t n,
+                  void* stream);
 
 /* ---- the contractions ------------------------------------------------------ */
 /*

@@ -13,6 +13,7 @@ import torch
 from . import _build
 
 QNN_OK = 0
+QNN_EUNSUPPORTED = -2
 STORE_F32, STORE_BIN, STORE_T2, STORE_I4, STORE_I8, STORE_U8 = 0, 1, 2, 4, 8, 16
 STORE_F32_IMAGE, STORE_F32_UNIT = 17, 18      # float32 input with a declared domain (first layer; qnn_abi.h)
 W_FLOAT, W_BINARY, W_QUANT, W_TERNARY = 0, 1, 2, 3
@@ -26,6 +27,7 @@ EXPORTS = [
     "qnn_prepack_weights", "qnn_free_weights", "qnn_weights_dequant", "qnn_weights_check",
     "qnn_conv2d_forward", "qnn_dense_forward", "qnn_conv2d_forward_f32in", "qnn_conv2d_workspace_bytes",
     "qnn_conv2d_dense_forward",
+    "qnn_fold_prepare", "qnn_fold_free", "qnn_fold_info", "qnn_fold_constants", "qnn_fold_eval",
 ]
 
 
@@ -34,7 +36,14 @@ class Epilogue(ctypes.Structure):
                 ("fn", ctypes.c_int32), ("act_bits", ctypes.c_int32),
                 ("pool", ctypes.c_int32), ("out_store", ctypes.c_int32),
                 ("res", ctypes.c_void_p), ("res_store", ctypes.c_int32), ("res_bits", ctypes.c_int32),
-                ("post_scale", ctypes.c_float), ("trick_c", ctypes.c_float), ("trick_s", ctypes.c_float)]
+                ("post_scale", ctypes.c_float), ("trick_c", ctypes.c_float), ("trick_s", ctypes.c_float),
+                ("fold", ctypes.c_void_p)]
+
+
+class FoldInfo(ctypes.Structure):
+    _fields_ = [("channels", ctypes.c_int32), ("folded", ctypes.c_int32), ("usable", ctypes.c_int32),
+                ("shortcut_codes", ctypes.c_int32), ("points", ctypes.c_int64),
+                ("acc_lo", ctypes.c_int32), ("acc_hi", ctypes.c_int32)]
 
 
 class QnnError(RuntimeError):
@@ -95,6 +104,11 @@ def load():
     lib.qnn_dense_forward.argtypes = [vp, vp, ci, ci, ci, ctypes.POINTER(Epilogue), vp, vp]
     lib.qnn_conv2d_dense_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue),
                                              ctypes.POINTER(Epilogue), vp, vp]
+    lib.qnn_fold_prepare.argtypes = [vp, ci, ci, ctypes.POINTER(Epilogue), vp, ctypes.POINTER(vp)]
+    lib.qnn_fold_free.argtypes = [vp]
+    lib.qnn_fold_info.argtypes = [vp, ctypes.POINTER(FoldInfo)]
+    lib.qnn_fold_constants.argtypes = [vp, vp, vp, vp]
+    lib.qnn_fold_eval.argtypes = [vp, ci, vp, vp, vp, sz, vp]
     lib.qnn_conv2d_workspace_bytes.argtypes = [vp, ci, ci, ci]
     lib.qnn_conv2d_workspace_bytes.restype = sz
     lib.qnn_conv2d_forward_f32in.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.POINTER(Epilogue), vp,
@@ -279,12 +293,65 @@ def out_hw(size, k, stride, same_pad):
 
 
 def make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res=None, res_store=STORE_F32,
-                  res_bits=0, post_scale=1.0, trick=None):
+                  res_bits=0, post_scale=1.0, trick=None, fold=None):
     """trick: None (the reference's lr-multiplier identity trick is the identity) or the (c, s) float32 pair of its
-    OUTPUT side, `faithful_trick(klm, promotion)`."""
+    OUTPUT side, `faithful_trick(klm, promotion)`.  fold: a Fold prepared for exactly this layer and epilogue."""
     tc, ts = (float(trick[0]), float(trick[1])) if trick is not None else (0.0, 0.0)
     return Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store,
-                    ptr(res).value, res_store, res_bits, float(post_scale), tc, ts)
+                    ptr(res).value, res_store, res_bits, float(post_scale), tc, ts,
+                    fold.handle.value if fold is not None else None)
+
+
+class Fold:
+    """Owner of a qnn_fold_t: the epilogue of one layer (bias, BN, [shortcut merge], quantized_tanh) folded to a slope and
+    an accumulator offset per channel and PROVEN equal to the float32 chain on every point of the layer's accumulator
+    domain (qnn_fold_prepare, include/qnn_abi.h).  `usable` False = some channel has no exact fold: the kernels keep the
+    chain (bit-identical results either way).  Returns None from `try_prepare` where the library folds nothing
+    (other bit widths, float32 shortcut, ...)."""
+
+    def __init__(self, w, x_store, x_bits, bn_inv, bn_shift, fn, act_bits, out_store, res=None, res_store=STORE_F32,
+                 res_bits=0, post_scale=1.0):
+        self._keep = (w, bn_inv, bn_shift)
+        self.handle = ctypes.c_void_p(None)
+        epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, 1, out_store, res, res_store, res_bits, post_scale)
+        rc = load().qnn_fold_prepare(w.handle, x_store, x_bits, ctypes.byref(epi), stream_ptr(), ctypes.byref(self.handle))
+        self.rc = rc
+        if rc != QNN_OK:
+            self.handle = ctypes.c_void_p(None)
+            if rc != QNN_EUNSUPPORTED:
+                check(rc, "qnn_fold_prepare")
+            return
+        info = FoldInfo()
+        check(load().qnn_fold_info(self.handle, ctypes.byref(info)), "qnn_fold_info")
+        self.channels, self.folded, self.usable = info.channels, info.folded, bool(info.usable)
+        self.points, self.acc_lo, self.acc_hi = info.points, info.acc_lo, info.acc_hi
+        self.shortcut_codes = info.shortcut_codes
+
+    @classmethod
+    def try_prepare(cls, *a, **kw):
+        f = cls(*a, **kw)
+        return f if f.handle.value else None
+
+    def constants(self, device):
+        A = torch.empty(self.channels, dtype=torch.float32, device=device)
+        b = torch.empty(self.channels, dtype=torch.int32, device=device)
+        check(load().qnn_fold_constants(self.handle, ptr(A), ptr(b), stream_ptr()), "qnn_fold_constants")
+        return A, b
+
+    def eval(self, c, acc, sc=None):
+        """The folded epilogue of channel c on int32 CUDA tensors acc (true accumulator units) [and sc]: int32 codes."""
+        out = torch.empty_like(acc)
+        check(load().qnn_fold_eval(self.handle, int(c), ptr(acc), ptr(sc), ptr(out), acc.numel(), stream_ptr()),
+              "qnn_fold_eval")
+        return out
+
+    def __del__(self):
+        try:
+            if self.handle and self.handle.value and _lib is not None:
+                _lib.qnn_fold_free(self.handle)
+                self.handle = ctypes.c_void_p(None)
+        except Exception:
+            pass
 
 
 def faithful_trick(klm, promotion="nep50"):
@@ -303,7 +370,8 @@ def faithful_trick(klm, promotion="nep50"):
 
 
 def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
-           pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0, out=None, trick=None):
+           pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0, out=None, trick=None,
+           fold=None):
     """Run qnn_conv2d_forward; x is a float32 NHWC tensor, a uint8 NHWC tensor or an int32 packed tensor.
     Returns (y, Hp, Wp): y float32 (N,Hp,Wp,cout) or int32 (N*Hp*Wp, words); `out` = a tensor of that shape to write
     into instead of a fresh one."""
@@ -320,13 +388,11 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
         if tuple(out.shape) != shape or out.dtype != dt or not out.is_contiguous() or out.device != x.device:
             raise QnnError("conv2d: `out` must be a contiguous %s tensor of shape %s on %s" % (dt, shape, x.device))
         y = out
-    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale, trick)
+    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale, trick, fold)
     check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
                                     ptr(y), stream_ptr()), "qnn_conv2d_forward")
     return y, Ho, Wo
 
-
-QNN_EUNSUPPORTED = -2
 
 
 def conv2d_dense(wc, wd, x, x_store, x_bits, N, H, W, c_inv, c_shift, c_fn, c_act_bits, d_inv, d_shift, out=None):
@@ -369,9 +435,9 @@ class BoundStep:
     pipeline's first step reads the caller's batch in place, its last step writes into the caller's result)."""
 
     def __init__(self, kind, w, x_store, x_bits, N, H, W, bn_inv, bn_shift, fn, act_bits, pool, out_store, x, y,
-                 trick=None):
-        self._keep = (w, bn_inv, bn_shift, x, y)
-        self._epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, trick=trick)
+                 trick=None, fold=None):
+        self._keep = (w, bn_inv, bn_shift, x, y, fold)
+        self._epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, trick=trick, fold=fold)
         self._x = x.data_ptr() if x is not None else 0
         self._y = y.data_ptr() if y is not None else 0
         lib = load()

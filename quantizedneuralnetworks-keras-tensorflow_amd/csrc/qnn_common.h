@@ -132,6 +132,8 @@ struct EpiArgs {
     float res_scale;           // 2^-(res_bits-1)
     float post_scale;
     float trick_c, trick_s;    // output-side identity trick of the reference ("faithful" mode); trick_s == 0: off
+    const float* fold_a;       // qnn_fold_t of this layer + epilogue (qnn_fold.h): per-channel slope, or nullptr = evaluate
+    const int32_t* fold_b;     // the float32 chain; per-channel accumulator offset in units of acc / 256
 };
 
 #ifdef __HIPCC__

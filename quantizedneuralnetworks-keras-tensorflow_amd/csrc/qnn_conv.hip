@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "qnn_common.h"
+#include "qnn_fold.h"
 #include "qnn_mfma_common.h"
 
 #ifndef QNN_XNOR_U
@@ -1135,6 +1136,22 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
     e->post_scale = epi->res ? epi->post_scale : 1.0f;
     e->trick_c = epi->trick_s != 0.0f ? epi->trick_c : 0.0f;
     e->trick_s = epi->trick_s;
+    e->fold_a = nullptr;
+    e->fold_b = nullptr;
+    if (epi->fold) {
+        // the fold must have been prepared for exactly this layer and epilogue; a handle whose sweep found a differing
+        // point on some channel (folded < cout) is accepted and ignored: the kernels evaluate the float32 chain
+        const qnn_fold* f = epi->fold;
+        const bool has_res = epi->res != nullptr;
+        QNN_REQUIRE(f->w == w && f->bn_inv == epi->bn_inv && f->bn_shift == epi->bn_shift && f->fn == epi->fn &&
+                        f->act_bits == epi->act_bits && f->out_store == epi->out_store && f->x_bits == xshift + 1 &&
+                        (f->has_res != 0) == has_res &&
+                        (!has_res || (f->res_store == epi->res_store && f->res_bits == epi->res_bits &&
+                                      f->post_scale == epi->post_scale)) &&
+                        epi->trick_s == 0.0f,
+                    QNN_EINVAL, "epilogue: the fold handle was prepared for another layer / epilogue (qnn_fold_prepare)");
+        if (f->folded == f->cout) { e->fold_a = f->d_a; e->fold_b = f->d_b; }
+    }
     QNN_REQUIRE(epi->trick_s == 0.0f || (epi->trick_s > 0.0f && epi->trick_s < 1.0e6f), QNN_EINVAL,
                 "epilogue: trick_s=%g (the layer's kernel_lr_multiplier, or 0)", (double)epi->trick_s);
     if (epi->res) {

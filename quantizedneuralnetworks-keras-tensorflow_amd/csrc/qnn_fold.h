@@ -1,0 +1,57 @@
+// The epilogue as integer thresholds (qnn_abi.h, qnn_fold_prepare): device functions shared by the kernels that use a
+// fold and by the prepare / verify / eval kernels of qnn_fold.hip -- ONE definition, so what the sweep proves is what
+// the kernels execute.
+//
+// Per output channel the reference's chain  bias_add -> BatchNormalization -> [+ shortcut, * 0.5] -> quantized_tanh
+// (models/vgg.py:16-17, models/resnet.py:59-63,127-129; float32, one rounding per operation) is a monotone step function
+// of the integer accumulator.  Folded form, on the accumulator in matrix-pipe units accw = 256 * acc (both int4 operands
+// are widened to code * 16) with the per-channel offset beta already added (it is the MFMA's initial accumulator):
+//     u  = float(accw) * A                          v_cvt_f32_i32, v_mul_f32            (exact conversion: |accw| < 2^24)
+//     T  = snorm16(u) = rint(clamp(u, -1, 1) * 32767)   v_cvt_pknorm_i16_f32, two values per instruction
+//   no shortcut:   T is Q12 (code * 4096 + fraction), saturated to the 4-bit code range by the conversion itself;
+//   shortcut sc:   T is Q11;  W = sat16(T + (sc + 8) * 1024);  T' = sat16(W + W)   two v_pk_add_i16 clamp per pair
+//     code = T >> 12 (arithmetic): the top nibble of each 16-bit half IS the two's-complement code.
+// Pairs of values live in the two halves of one register from the conversion on.
+#pragma once
+#include "qnn_common.h"
+
+#ifdef __HIPCC__
+typedef short qnn_s2 __attribute__((ext_vector_type(2)));
+
+// two accumulators (offset included) -> two saturated Q12 (no shortcut) / Q11 (shortcut) values
+__device__ __forceinline__ uint32_t qnn_fold_pair(int accw0, int accw1, float a0, float a1) {
+    const float u0 = __fmul_rn((float)accw0, a0), u1 = __fmul_rn((float)accw1, a1);
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(u0, u1));
+}
+// shortcut merge: s = ((sc + 8) << 10) in both halves (offset-coded shortcut codes at Q11 / 2)
+__device__ __forceinline__ uint32_t qnn_fold_merge(uint32_t t, uint32_t s) {
+    const qnn_s2 w = __builtin_elementwise_add_sat(__builtin_bit_cast(qnn_s2, t), __builtin_bit_cast(qnn_s2, s));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(w, w));
+}
+// the 4-bit codes of a pair (tests / verifier; the kernels pick the nibbles up with v_perm_b32 / v_bfi_b32)
+__device__ __forceinline__ int qnn_fold_code_lo(uint32_t t) { return (int)(short)(t & 0xFFFFu) >> 12; }
+__device__ __forceinline__ int qnn_fold_code_hi(uint32_t t) { return (int)t >> 28; }
+// one value, both forms (sc ignored without a shortcut)
+__device__ __forceinline__ int qnn_fold_code(int accw, float a, bool res, int sc) {
+    uint32_t t = qnn_fold_pair(accw, accw, a, a);
+    if (res) t = qnn_fold_merge(t, (uint32_t)((sc + 8) << 10) * 0x00010001u);
+    return qnn_fold_code_lo(t);
+}
+#endif
+
+// host side of the handle
+struct qnn_fold {
+    const qnn_weights* w;          // the layer it was built for
+    int x_store, x_bits;
+    const float* bn_inv;           // the epilogue it was built for (pointer identity is checked at launch)
+    const float* bn_shift;
+    int fn, act_bits, out_store;
+    int has_res, res_store, res_bits;
+    float post_scale;
+    int cout;
+    float* d_a;                    // [cout] slope
+    int32_t* d_b;                  // [cout] offset, units of acc / 256
+    int folded;                    // channels whose fold reproduced the chain on the whole domain
+    long long points;
+    int acc_lo, acc_hi;
+};

@@ -1,0 +1,327 @@
+// qnn_fold_prepare / _free / _info / _constants / _eval (qnn_abi.h): the epilogue of a low-bit convolution as integer
+// thresholds, PROVEN against the float32 chain on every point of the layer's accumulator domain.
+//
+// What is folded (reference): K.bias_add (binary_layers.py:179-180, quantized_layers.py:186-187), the inference
+// BatchNormalization behind it (models/vgg.py:16, models/resnet.py:61), the residual merge keras.layers.add + Lambda(x * 0.5)
+// (models/resnet.py:127-128) and quantized_tanh (quantized_ops.py:87-100, models/vgg.py:17, models/resnet.py:129).
+// The un-folded kernels evaluate that chain in float32 with one rounding per operation (qnn_epi_value, qnn_epi_residual,
+// qnn_epi_code in qnn_common.h); this file evaluates THE SAME inline functions on every accumulator value the layer can
+// produce and searches, per channel, the two constants of the folded form (qnn_fold.h).
+//
+// One workgroup per output channel:
+//   1. domain: acc in [sum_k min(w_k a_lo, w_k a_hi), sum_k max(..)] from the int8 weight image and the input codes' range;
+//   2. the chain's thresholds T(k, sc) = first accumulator with code >= k, by bisection (every float32 step is monotone);
+//   3. for a few float32 neighbours of the real-number slope: the folded form's thresholds X(k, sc) by bisection on the
+//      very device function the kernels inline, and the interval of offsets beta for which X and T select the same
+//      accumulators; the middle of a non-empty interval is the candidate;
+//   4. PROOF: the candidate is compared with the chain on every (accumulator, shortcut code) point of the domain; only a
+//      candidate with zero differing points is accepted.  Steps 2-3 merely find candidates; step 4 is what is relied on.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qnn_fold.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kCandidates = 33;      // slope candidates: the rounded real-number slope and +-1 .. +-16 float32 neighbours
+
+struct FoldProblem {
+    EpiArgs e;                       // chain constants; e.scale = 2^-(wshift + xshift), e.res unused
+    const int8_t* wq8;               // int8 weight image [cout][K], code * 16
+    int K;
+    int a_lo, a_hi;                  // range of the input codes
+    int has_res;
+    float res_scale, post_scale;     // shortcut value = code * res_scale; merged = (shortcut + y) * post_scale
+    float* A;
+    int32_t* beta;
+    int32_t* status;                 // per channel: 1 folded, 0 not
+    int32_t* dom;                    // per channel: lo, hi
+    unsigned long long* points;      // per channel: points compared
+};
+
+// the chain, exactly as k_conv_generic evaluates it (qnn_conv.hip)
+__device__ __forceinline__ int chain_code(const FoldProblem& p, int c, int acc, int sc) {
+    float v = __fmul_rn((float)acc, p.e.scale);
+    v = qnn_epi_value(v, c, p.e);
+    if (p.has_res) v = __fmul_rn(__fadd_rn(__fmul_rn((float)sc, p.res_scale), v), p.post_scale);
+    return qnn_epi_code(v, p.e);
+}
+
+__device__ __forceinline__ long long block_reduce(long long v, bool want_max, long long* sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (t < s) sh[t] = want_max ? (sh[t] > sh[t + s] ? sh[t] : sh[t + s]) : (sh[t] < sh[t + s] ? sh[t] : sh[t + s]);
+        __syncthreads();
+    }
+    const long long r = sh[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ long long block_sum(long long v, long long* sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (t < s) sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    const long long r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+constexpr long long kInf = (1LL << 60);
+
+__global__ __launch_bounds__(kThreads) void k_fold_prepare(FoldProblem p) {
+    __shared__ long long sh[kThreads];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int m = (int)p.e.act_m;                    // 8: codes -m .. m-1
+    // ---- 1. domain ----
+    long long lo = 0, hi = 0;
+    for (int k = t; k < p.K; k += kThreads) {
+        const int w = (int)p.wq8[(size_t)c * p.K + k] / 16;       // the image holds code * 16 exactly
+        const int x0 = w * p.a_lo, x1 = w * p.a_hi;
+        lo += x0 < x1 ? x0 : x1;
+        hi += x0 < x1 ? x1 : x0;
+    }
+    lo = block_sum(lo, sh);
+    hi = block_sum(hi, sh);
+    if (t == 0) { p.dom[2 * c] = (int)lo; p.dom[2 * c + 1] = (int)hi; p.status[c] = 0; p.A[c] = 0.0f; p.beta[c] = 0; p.points[c] = 0; }
+    // ---- real-number constants of the chain ----
+    const double inv = p.e.bn_inv ? (double)p.e.bn_inv[c] : 1.0, shift = p.e.bn_inv ? (double)p.e.bn_shift[c] : 0.0;
+    const double bias = p.e.bias ? (double)p.e.bias[c] : 0.0;
+    const double post = p.has_res ? (double)p.post_scale : 1.0;
+    const double g = (double)p.e.scale * inv * post * (double)m;              // codes per accumulator step
+    const double b0 = (bias * inv + shift) * post * (double)m;                // code at accumulator 0 (shortcut 0)
+    if (!(g == g) || !(b0 == b0) || g == 0.0 || fabs(g) > 1.0e6 || fabs(g) < 1.0e-9 || fabs(b0) > 1.0e9) return;   // uniform
+    const int dir = g < 0.0 ? -1 : 1;
+    const int nsc = p.has_res ? 2 * m : 1, sc0 = p.has_res ? -m : 0;
+    const long long zlo = dir > 0 ? lo : -hi, zhi = dir > 0 ? hi : -lo;       // z = dir * acc: the chain is non-decreasing in z
+    const double q = p.has_res ? 2048.0 : 4096.0;                             // Q11 / Q12
+    const double a_nom = g * q / (32767.0 * 256.0);                           // per matrix-pipe accumulator unit (acc * 256)
+    const double beta_nom = (b0 + 0.5 - (p.has_res ? 4.0 : 0.0)) * 256.0 / g;  // in those units
+    if (fabs(beta_nom) > 1.0e9) return;
+    const long long bnz = (long long)llrint(beta_nom) * dir;                  // nominal offset in the z domain
+    // this thread's (k, sc)
+    const int nk = 2 * m - 1;
+    const bool active = t < nk * nsc;
+    const int k = active ? (t % nk) - (m - 1) : 0;
+    const int sc = active ? sc0 + t / nk : 0;
+    // ---- 2. the chain's threshold: first z in [zlo, zhi] with code >= k (zhi + 1: none) ----
+    long long Tz = zhi + 1;
+    if (active) {
+        long long a = zlo, b = zhi + 1;                                       // invariant: code(z) >= k for z >= b (or b = zhi + 1)
+        while (a < b) {
+            const long long mid = a + ((b - a) >> 1);
+            if (chain_code(p, c, (int)(dir * mid), sc) >= k) b = mid; else a = mid + 1;
+        }
+        Tz = a;
+    }
+    // ---- 3. + 4. candidates ----
+    const long long npts = (zhi - zlo + 1) * nsc;
+    for (int cand = 0; cand < kCandidates; ++cand) {
+        const int step = cand == 0 ? 0 : ((cand & 1) ? (cand + 1) / 2 : -(cand / 2));
+        float A = (float)a_nom;
+        A = __int_as_float(__float_as_int(A) + step);                          // float32 neighbours (same sign, same binade nearly always)
+        const bool res = p.has_res != 0;
+        // folded thresholds in the z domain: accw = dir * z'
+        long long blo = -kInf, bhi = kInf;
+        if (active) {
+            const long long Zlo = 256 * zlo + bnz - (1 << 20), Zhi = 256 * zhi + bnz + (1 << 20);
+            long long X;
+            if (qnn_fold_code((int)(dir * Zhi), A, res, sc) < k) X = kInf;
+            else if (qnn_fold_code((int)(dir * Zlo), A, res, sc) >= k) X = -kInf;
+            else {
+                long long a = Zlo, b = Zhi;                                    // F(a) < k <= F(b)
+                while (b - a > 1) {
+                    const long long mid = a + ((b - a) >> 1);
+                    if (qnn_fold_code((int)(dir * mid), A, res, sc) >= k) b = mid; else a = mid;
+                }
+                X = b;
+            }
+            if (Tz > zlo && Tz <= zhi) {               // threshold inside the domain
+                if (X == kInf || X == -kInf) { blo = kInf; bhi = -kInf; }
+                else { blo = X - 256 * Tz; bhi = X - 256 * (Tz - 1) - 1; }
+            } else if (Tz == zlo) {                    // the chain is >= k everywhere
+                if (X == kInf) { blo = kInf; bhi = -kInf; }
+                else if (X != -kInf) blo = X - 256 * zlo;
+            } else {                                   // never
+                if (X == -kInf) { blo = kInf; bhi = -kInf; }
+                else if (X != kInf) bhi = X - 256 * zhi - 1;
+            }
+        }
+        blo = block_reduce(blo, true, sh);
+        bhi = block_reduce(bhi, false, sh);
+        if (blo > bhi) continue;                       // uniform
+        long long bz;
+        if (blo > -kInf / 2 && bhi < kInf / 2) bz = blo + ((bhi - blo) >> 1);
+        else bz = bnz < blo ? blo : bnz > bhi ? bhi : bnz;
+        if (bz > (1LL << 30) || bz < -(1LL << 30)) continue;
+        const int beta = (int)(dir * bz);
+        // ---- 4. proof: every point of the domain ----
+        long long bad = 0;
+        for (long long i = t; i < npts; i += kThreads) {
+            const int s = sc0 + (int)(i % nsc);
+            const int acc = (int)(dir * (zlo + i / nsc));
+            bad += chain_code(p, c, acc, s) != qnn_fold_code(256 * acc + beta, A, res, s);
+        }
+        bad = block_sum(bad, sh);
+        if (bad == 0) {
+            if (t == 0) { p.A[c] = A; p.beta[c] = beta; p.status[c] = 1; p.points[c] = (unsigned long long)npts; }
+            return;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_fold_eval(const float* __restrict__ A, const int32_t* __restrict__ beta, int c,
+                                                        int has_res, const int32_t* __restrict__ acc,
+                                                        const int32_t* __restrict__ sc, int32_t* __restrict__ codes, size_t n) {
+    const float a = A[c];
+    const int b = beta[c];
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
+        codes[i] = qnn_fold_code(256 * acc[i] + b, a, has_res != 0, has_res ? sc[i] : 0);
+}
+
+}  // namespace
+
+extern "C" int qnn_fold_prepare(const qnn_weights_t* w, int x_store, int x_bits, const qnn_epilogue_t* epi, void* stream,
+                                qnn_fold_t** out) {
+    QNN_REQUIRE(w && epi && out, QNN_EINVAL, "qnn_fold_prepare: null pointer");
+    *out = nullptr;
+    QNN_REQUIRE(w->store == QNN_STORE_I4 && w->d_mfma && x_store == QNN_STORE_I4, QNN_EUNSUPPORTED,
+                "qnn_fold_prepare: needs weights prepacked for QNN_STORE_I4 with a matrix-pipe image and QNN_STORE_I4 input "
+                "(store=%d x_store=%d)", w->store, x_store);
+    QNN_REQUIRE(x_bits >= 1 && x_bits <= 4, QNN_EINVAL, "qnn_fold_prepare: x_bits=%d", x_bits);
+    QNN_REQUIRE(epi->fn == QNN_FN_QUANTIZED_TANH && epi->act_bits == 4 && epi->out_store == QNN_STORE_I4, QNN_EUNSUPPORTED,
+                "qnn_fold_prepare: only quantized_tanh with 4-bit codes stored as QNN_STORE_I4 is folded (fn=%d act_bits=%d "
+                "out_store=%d)", epi->fn, epi->act_bits, epi->out_store);
+    QNN_REQUIRE(epi->trick_s == 0.0f, QNN_EUNSUPPORTED, "qnn_fold_prepare: the output-side trick is not folded");
+    QNN_REQUIRE((epi->bn_inv == nullptr) == (epi->bn_shift == nullptr), QNN_EINVAL,
+                "qnn_fold_prepare: bn_inv and bn_shift must both be set or both be NULL");
+    const bool has_res = epi->res != nullptr;
+    if (has_res)
+        QNN_REQUIRE(epi->res_store == QNN_STORE_I4 && epi->res_bits == 4 && epi->post_scale == 0.5f, QNN_EUNSUPPORTED,
+                    "qnn_fold_prepare: a shortcut must be 4-bit QNN_STORE_I4 codes merged with post_scale 0.5 (res_store=%d "
+                    "res_bits=%d post_scale=%g)", epi->res_store, epi->res_bits, (double)epi->post_scale);
+    hipStream_t s = (hipStream_t)stream;
+    qnn_fold* f = (qnn_fold*)calloc(1, sizeof(qnn_fold));
+    QNN_REQUIRE(f, QNN_ENOMEM, "qnn_fold_prepare: out of host memory");
+    f->w = w; f->x_store = x_store; f->x_bits = x_bits;
+    f->bn_inv = epi->bn_inv; f->bn_shift = epi->bn_shift;
+    f->fn = epi->fn; f->act_bits = epi->act_bits; f->out_store = epi->out_store;
+    f->has_res = has_res ? 1 : 0; f->res_store = has_res ? epi->res_store : 0; f->res_bits = has_res ? epi->res_bits : 0;
+    f->post_scale = has_res ? epi->post_scale : 1.0f;
+    f->cout = w->cout;
+    int32_t *d_status = nullptr, *d_dom = nullptr;
+    unsigned long long* d_points = nullptr;
+    auto fail = [&](int code) {
+        if (f->d_a) (void)hipFree(f->d_a);
+        if (f->d_b) (void)hipFree(f->d_b);
+        if (d_status) (void)hipFree(d_status);
+        if (d_dom) (void)hipFree(d_dom);
+        if (d_points) (void)hipFree(d_points);
+        free(f);
+        return code;
+    };
+#define FOLD_HIP(expr)                                                                                           \
+    do {                                                                                                         \
+        hipError_t _e = (expr);                                                                                  \
+        if (_e != hipSuccess) {                                                                                  \
+            qnn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);            \
+            return fail(QNN_EHIP);                                                                               \
+        }                                                                                                        \
+    } while (0)
+    FOLD_HIP(hipMalloc(&f->d_a, sizeof(float) * w->cout));
+    FOLD_HIP(hipMalloc(&f->d_b, sizeof(int32_t) * w->cout));
+    FOLD_HIP(hipMalloc(&d_status, sizeof(int32_t) * w->cout));
+    FOLD_HIP(hipMalloc(&d_dom, sizeof(int32_t) * 2 * w->cout));
+    FOLD_HIP(hipMalloc(&d_points, sizeof(unsigned long long) * w->cout));
+    FoldProblem p;
+    memset((void*)&p, 0, sizeof(p));
+    p.e.bias = w->d_bias;
+    p.e.bn_inv = epi->bn_inv; p.e.bn_shift = epi->bn_shift;
+    p.e.scale = ldexpf(1.0f, -(w->wshift + x_bits - 1));
+    p.e.act_m = 8.0f;
+    p.e.fn = epi->fn; p.e.out_store = epi->out_store;
+    p.wq8 = (const int8_t*)w->d_mfma;
+    p.K = w->kh * w->kw * w->cin;
+    p.a_lo = x_bits == 1 ? -1 : -(1 << (x_bits - 1));
+    p.a_hi = x_bits == 1 ? 1 : (1 << (x_bits - 1)) - 1;
+    p.has_res = f->has_res;
+    p.res_scale = ldexpf(1.0f, -(4 - 1));
+    p.post_scale = f->post_scale;
+    p.A = f->d_a; p.beta = f->d_b; p.status = d_status; p.dom = d_dom; p.points = d_points;
+    hipLaunchKernelGGL(k_fold_prepare, dim3((unsigned)w->cout), dim3(kThreads), 0, s, p);
+    FOLD_HIP(hipGetLastError());
+    int32_t* h_status = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)w->cout);
+    unsigned long long* h_points = (unsigned long long*)malloc(sizeof(unsigned long long) * (size_t)w->cout);
+    if (!h_status || !h_points) { free(h_status); free(h_points); qnn_set_error("qnn_fold_prepare: out of host memory"); return fail(QNN_ENOMEM); }
+    hipError_t he = hipMemcpyAsync(h_status, d_status, sizeof(int32_t) * w->cout, hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipMemcpyAsync(h_status + w->cout, d_dom, sizeof(int32_t) * 2 * w->cout, hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipMemcpyAsync(h_points, d_points, sizeof(unsigned long long) * w->cout, hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    if (he != hipSuccess) {
+        free(h_status); free(h_points);
+        qnn_set_error("qnn_fold_prepare: %s", hipGetErrorString(he));
+        return fail(QNN_EHIP);
+    }
+    f->folded = 0; f->points = 0;
+    f->acc_lo = 0; f->acc_hi = 0;
+    for (int c = 0; c < w->cout; ++c) {
+        f->folded += h_status[c] != 0;
+        f->points += (long long)h_points[c];
+        const int lo = h_status[w->cout + 2 * c], hi = h_status[w->cout + 2 * c + 1];
+        if (c == 0 || lo < f->acc_lo) f->acc_lo = lo;
+        if (c == 0 || hi > f->acc_hi) f->acc_hi = hi;
+    }
+    free(h_status); free(h_points);
+    (void)hipFree(d_status); (void)hipFree(d_dom); (void)hipFree(d_points);
+#undef FOLD_HIP
+    *out = f;
+    return QNN_OK;
+}
+
+extern "C" int qnn_fold_free(qnn_fold_t* f) {
+    if (!f) return QNN_OK;
+    if (f->d_a) (void)hipFree(f->d_a);
+    if (f->d_b) (void)hipFree(f->d_b);
+    free(f);
+    return QNN_OK;
+}
+
+extern "C" int qnn_fold_info(const qnn_fold_t* f, qnn_fold_info_t* info) {
+    QNN_REQUIRE(f && info, QNN_EINVAL, "qnn_fold_info: null pointer");
+    info->channels = f->cout;
+    info->folded = f->folded;
+    info->usable = f->folded == f->cout ? 1 : 0;
+    info->shortcut_codes = f->has_res ? 16 : 1;
+    info->points = f->points;
+    info->acc_lo = f->acc_lo;
+    info->acc_hi = f->acc_hi;
+    return QNN_OK;
+}
+
+extern "C" int qnn_fold_constants(const qnn_fold_t* f, float* A, int32_t* beta, void* stream) {
+    QNN_REQUIRE(f && A && beta, QNN_EINVAL, "qnn_fold_constants: null pointer");
+    QNN_HIP(hipMemcpyAsync(A, f->d_a, sizeof(float) * f->cout, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    QNN_HIP(hipMemcpyAsync(beta, f->d_b, sizeof(int32_t) * f->cout, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return QNN_OK;
+}
+
+extern "C" int qnn_fold_eval(const qnn_fold_t* f, int c, const int32_t* acc, const int32_t* sc, int32_t* codes, size_t n,
+                             void* stream) {
+    QNN_REQUIRE(f && acc && codes, QNN_EINVAL, "qnn_fold_eval: null pointer");
+    QNN_REQUIRE(c >= 0 && c < f->cout, QNN_EINVAL, "qnn_fold_eval: channel %d of %d", c, f->cout);
+    QNN_REQUIRE(!f->has_res || sc, QNN_EINVAL, "qnn_fold_eval: this fold merges a shortcut: sc must be given");
+    if (n == 0) return QNN_OK;
+    size_t blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(k_fold_eval, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, f->d_a, f->d_b, c,
+                       f->has_res, acc, sc, codes, n);
+    QNN_HIP(hipGetLastError());
+    return QNN_OK;
+}

@@ -34,6 +34,7 @@
 // that the 18 filter fragments stay in registers.  Any width: the last strip of a row is partly out of the image (its
 // loads and stores get out-of-range offsets).
 #include "qnn_mfma_common.h"
+#include "qnn_fold.h"
 
 #ifndef QNN_STRIP16_WPS
 #define QNN_STRIP16_WPS 6        // waves per SIMD (= persistent workgroups per CU): Cin 16 needs 51-67 VGPRs
@@ -43,6 +44,15 @@
 #endif
 #ifndef QNN_STRIP64_WPS
 #define QNN_STRIP64_WPS 2        // Cin 64 (two 32-channel halves per strip): 164-200 VGPRs, spills at 3 per SIMD
+#endif
+#ifndef QNN_STRIP16_DEPTH
+#define QNN_STRIP16_DEPTH 6      // input rows requested ahead of the row being computed (see the ring in k_conv_strip)
+#endif
+#ifndef QNN_STRIP32_DEPTH
+#define QNN_STRIP32_DEPTH 3
+#endif
+#ifndef QNN_STRIP64_DEPTH
+#define QNN_STRIP64_DEPTH 3
 #endif
 
 namespace {
@@ -62,7 +72,12 @@ __device__ __forceinline__ void strip_block_map(int& xw, int& yblk) {
     }
 }
 
-template <int CIN, int NT, int RES, bool BIAS>   // RES: 0 none, 1 packed int4 shortcut, 2 float32 shortcut
+// FOLD: the epilogue as integer thresholds (qnn_fold.h; e.fold_a / e.fold_b, proven equal to the float32 chain on the
+// layer's whole accumulator domain by qnn_fold_prepare): the offset is the MFMA's initial accumulator, then per value
+// cvt + mul, per pair one v_cvt_pknorm_i16_f32 (+ two v_pk_add_i16 clamp with a shortcut), and the nibbles of a lane's
+// field are gathered with two v_perm_b32 + shift + v_bfi_b32 (NT = 2) instead of cvt, [add], mul, add, [bfe, cvt, fma],
+// add, v_med3 and a shift-or per value.
+template <int CIN, int NT, int RES, bool BIAS, bool FOLD>   // RES: 0 none, 1 packed int4 shortcut, 2 float32 shortcut
 __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RES == 2 ? 2 : QNN_STRIP32_WPS) : QNN_STRIP64_WPS)) void k_conv_strip(MfmaGeom mg, EpiArgs e,
                                                                  const uint8_t* __restrict__ x,
                                                                  const uint8_t* __restrict__ wq8,
@@ -128,6 +143,18 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
             nshift[nt][i >> 1][i & 1] = __fmul_rn(shift, cfold);
         }
     const v2f rcoef2 = {rcoef, rcoef};
+    // folded epilogue: per-channel slope and accumulator offset (the MFMA chain starts from the offset)
+    static_assert(!FOLD || RES != 2, "the float32 shortcut is not folded");
+    float fa[NT][4];
+    v4i binit[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = nbase + 4 * NT * kq + 4 * nt + i;
+            fa[nt][i] = FOLD ? e.fold_a[c] : 0.0f;
+            binit[nt][i] = FOLD ? e.fold_b[c] : 0;
+        }
     // round-half-even + clamp + offset code in the integer domain: as_int(u + (1.5*2^23 + 8)) = 0x4B400008 + rint(u)
     // for |u| < 2^22 and is monotone in u everywhere, so a signed integer med3 clamps it; the low nibble is code + 8
     constexpr float kMagic = 12582920.0f;
@@ -173,14 +200,18 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
         int rvoff = RES == 2 ? (pvalid ? ((y0 * g.W + xs + r) * g.cout + nbase + 4 * NT * kq) * 4 : (int)0x80000000)
                              : ovoff;                                           // + nt*16 (f32: the next four floats)
 
-        // Loads are requested THREE rows ahead (a ring of three input-row register sets and three shortcut registers):
-        // vmcnt retires in issue order, so a wave that waits for the oldest request keeps two rows of younger ones in
-        // flight.  (Measured neutral against a distance of one row at 5-6 waves per SIMD -- the SIMD issues an
-        // instruction every ~6 cycles either way, 70 % of its slots -- kept because it is what lower occupancy needs.)
+        // Loads are requested D rows ahead (a ring of D raw input-row register sets and D shortcut registers): vmcnt retires
+        // in issue order, so a wave that waits for the oldest request keeps D - 1 rows of younger ones in flight.  Round 4:
+        // with the folded epilogue the kernels are no longer bound by instruction issue but by the bytes they keep in
+        // flight (6144 waves x 3 rows x 128 unique bytes = 2.4 MB against ~1 us of loaded HBM latency = the 2.4 TB/s they
+        // reached): the ring depth is a compile-time constant per channel count (QNN_STRIP*_DEPTH, a multiple of 3).
+        constexpr int D = RES == 2 ? 3          // (the float32 shortcut of a projection block: 16 bytes per lane, row and tile)
+                          : CIN == 16 ? QNN_STRIP16_DEPTH : CIN == 32 ? QNN_STRIP32_DEPTH : QNN_STRIP64_DEPTH;
+        static_assert(D % 3 == 0 && D >= 3, "the row loop is unrolled D times and rotates three operand sets");
         v4i X[3][ST];
-        uint2 raw[3][ST];
-        uint32_t rs[3][NT];                            // packed shortcut: [.][0] holds the lane's whole 2*NT-byte field
-        float4 rf[3][NT];
+        uint2 raw[D][ST];
+        uint32_t rs[D][NT];                            // packed shortcut: [.][0] holds the lane's whole 2*NT-byte field
+        float4 rf[D][NT];
         auto load_row = [&](uint2 (&dst)[ST]) {
 #pragma unroll
             for (int st = 0; st < ST; ++st) {
@@ -199,33 +230,39 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
                     df[nt] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, rvoff + 16 * nt, 0, 0));
             rvoff += rrowb;
         };
-        load_row(raw[0]);                              // row y0 - 1
-        load_row(raw[1]);                              // row y0
-        load_row(raw[2]);                              // row y0 + 1
-        if constexpr (RES != 0) { load_res(rs[0], rf[0]); load_res(rs[1], rf[1]); load_res(rs[2], rf[2]); }   // rows y0 .. y0+2
+        {
+            uint2 t0[ST], t1[ST];
+            load_row(t0);                              // row y0 - 1
+            load_row(t1);                              // row y0
 #pragma unroll
-        for (int st = 0; st < ST; ++st) X[0][st] = widen(raw[0][st]);
-        load_row(raw[0]);                              // row y0 + 2
+            for (int d = 0; d < D; ++d) load_row(raw[d]);                       // rows y0 + 1 .. y0 + D
+            if constexpr (RES != 0) {
 #pragma unroll
-        for (int st = 0; st < ST; ++st) X[1][st] = widen(raw[1][st]);
-        load_row(raw[1]);                              // row y0 + 3
+                for (int d = 0; d < D; ++d) load_res(rs[d], rf[d]);             // rows y0 .. y0 + D - 1
+            }
+#pragma unroll
+            for (int st = 0; st < ST; ++st) X[0][st] = widen(t0[st]);
+#pragma unroll
+            for (int st = 0; st < ST; ++st) X[1][st] = widen(t1[st]);
+        }
 
-        // one output row yy = y0 + j: X slots a / b / c = j, j+1, j+2 (mod 3) hold input rows yy-1 / yy / yy+1; ring slot c
-        // holds row yy+1 (consumed here, refilled with row yy+4); shortcut slot a holds row yy (refilled with row yy+3)
+        // one output row yy = y0 + j: X slots a / b / c = j, j+1, j+2 (mod 3) hold input rows yy-1 / yy / yy+1; ring slot
+        // j mod D holds row yy+1 (consumed here, refilled with row yy+1+D); shortcut slot j mod D holds row yy (refilled
+        // with row yy+D)
         auto body = [&](v4i (&Xa)[ST], v4i (&Xb)[ST], v4i (&Xc)[ST], uint2 (&rw)[ST], uint32_t (&rsc)[NT],
                         float4 (&rfc)[NT]) {
 #pragma unroll
             for (int st = 0; st < ST; ++st) Xc[st] = widen(rw[st]);
-            load_row(rw);                              // row yy + 4
+            load_row(rw);                              // row yy + 1 + D
             uint32_t rcur[NT];
             float4 fcur[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { rcur[nt] = rsc[nt]; fcur[nt] = rfc[nt]; }
-            if constexpr (RES != 0) load_res(rsc, rfc);   // shortcut of row yy + 3
+            if constexpr (RES != 0) load_res(rsc, rfc);   // shortcut of row yy + D
             v4i acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const v4i z = {0, 0, 0, 0};
+                const v4i z = binit[nt];               // zeros, or the fold's per-channel offsets
                 acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[0][0][nt], Xa[0], z, 0, 0, 0);
 #pragma unroll
                 for (int st = 1; st < ST; ++st)
@@ -236,6 +273,42 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
 #pragma unroll
                 for (int st = 0; st < ST; ++st)
                     acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[2][st][nt], Xc[st], acc[nt], 0, 0, 0);
+            }
+            if constexpr (FOLD) {
+                // ---- folded epilogue (qnn_fold.h) ----
+                if constexpr (NT == 1) {
+                    // pairs (c0, c2), (c1, c3): codes in bits 12-15 / 28-31 of a pair
+                    uint32_t pe = qnn_fold_pair(acc[0][0], acc[0][2], fa[0][0], fa[0][2]);
+                    uint32_t po = qnn_fold_pair(acc[0][1], acc[0][3], fa[0][1], fa[0][3]);
+                    if constexpr (RES == 1) {
+                        // shortcut field (16 bits): nibbles -> offset codes (sc + 8) << 10 in the halves of a pair
+                        const uint32_t w = rcur[0] ^ 0x8888u;
+                        const uint32_t yy2 = __builtin_amdgcn_perm(0u, w, 0x0C010C00u);          // bytes (b0, 0, b1, 0)
+                        pe = qnn_fold_merge(pe, (yy2 & 0x000F000Fu) << 10);
+                        po = qnn_fold_merge(po, (yy2 & 0x00F000F0u) << 6);
+                    }
+                    const uint32_t mm = (po & 0xF000F000u) | ((pe >> 4) & ~0xF000F000u);          // v_bfi_b32: bytes 1, 3 = (c1:c0), (c3:c2)
+                    const uint32_t o16 = __builtin_amdgcn_perm(0u, mm, 0x0C0C0301u);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)o16, yr, ovoff, 0, 0);
+                } else {
+                    static_assert(NT <= 2, "a lane's fields must fit one word");
+                    uint32_t tp[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tp[j] = qnn_fold_pair(acc[0][j], acc[1][j], fa[0][j], fa[1][j]);   // (c_j, c_j+4)
+                    if constexpr (RES == 1) {
+                        const uint32_t w = rcur[0] ^ 0x88888888u;
+                        tp[0] = qnn_fold_merge(tp[0], (w & 0x000F000Fu) << 10);
+                        tp[1] = qnn_fold_merge(tp[1], (w & 0x00F000F0u) << 6);
+                        tp[2] = qnn_fold_merge(tp[2], (w & 0x0F000F00u) << 2);
+                        tp[3] = qnn_fold_merge(tp[3], (w & 0xF000F000u) >> 2);
+                    }
+                    const uint32_t uo = __builtin_amdgcn_perm(tp[3], tp[1], 0x07030501u);         // (c1, c3, c5, c7) in the high nibbles
+                    const uint32_t ue = __builtin_amdgcn_perm(tp[2], tp[0], 0x07030501u);         // (c0, c2, c4, c6)
+                    const uint32_t o32 = (uo & 0xF0F0F0F0u) | ((ue >> 4) & 0x0F0F0F0Fu);
+                    __builtin_amdgcn_raw_buffer_store_b32(o32, yr, ovoff, 0, 0);
+                }
+                ovoff += orowb;
+                return;
             }
             // ---- epilogue: the reference's op order, one rounding per operation ----
             uint32_t field[NT];
@@ -290,14 +363,21 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
             }
             ovoff += orowb;
         };
-#define STRIP_BODY(A, B, C) body(X[A], X[B], X[C], raw[C], rs[A], rf[A])
+#define STRIP_BODY(J) body(X[(J) % 3], X[((J) + 1) % 3], X[((J) + 2) % 3], raw[(J) % D], rs[(J) % D], rf[(J) % D])
         int yy = y0;
-        for (; yy + 3 <= y1; yy += 3) {
-            STRIP_BODY(0, 1, 2); STRIP_BODY(1, 2, 0); STRIP_BODY(2, 0, 1);
+        for (; yy + D <= y1; yy += D) {
+            STRIP_BODY(0); STRIP_BODY(1); STRIP_BODY(2);
+            if constexpr (D > 3) { STRIP_BODY(3); STRIP_BODY(4); STRIP_BODY(5); }
+            if constexpr (D > 6) { STRIP_BODY(6); STRIP_BODY(7); STRIP_BODY(8); }
+            if constexpr (D > 9) { STRIP_BODY(9); STRIP_BODY(10); STRIP_BODY(11); }
         }
+        static_assert(D <= 12, "unrolled by hand up to twelve rows");
         const int rem = y1 - yy;
-        if (rem > 0) STRIP_BODY(0, 1, 2);
-        if (rem > 1) STRIP_BODY(1, 2, 0);
+        if (rem > 0) STRIP_BODY(0);
+        if (rem > 1) STRIP_BODY(1);
+        if constexpr (D > 3) { if (rem > 2) STRIP_BODY(2); if (rem > 3) STRIP_BODY(3); if (rem > 4) STRIP_BODY(4); }
+        if constexpr (D > 6) { if (rem > 5) STRIP_BODY(5); if (rem > 6) STRIP_BODY(6); if (rem > 7) STRIP_BODY(7); }
+        if constexpr (D > 9) { if (rem > 8) STRIP_BODY(8); if (rem > 9) STRIP_BODY(9); if (rem > 10) STRIP_BODY(10); }
 #undef STRIP_BODY
     }
 }
@@ -308,7 +388,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
 // output row, so every output row simply requests its three input rows (one output row ahead) and widens them.
 // B operand of lane (pixel r, k-block): input pixel 2*(xs + r) - pl + dx.
 // ---------------------------------------------------------------------------------------------------------
-template <int CIN, int NT, bool BIAS>
+template <int CIN, int NT, bool BIAS, bool FOLD>
 __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(MfmaGeom mg, EpiArgs e,
                                                                              const uint8_t* __restrict__ x,
                                                                              const uint8_t* __restrict__ wq8,
@@ -359,6 +439,16 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
             nb[nt][i >> 1][i & 1] = BIAS ? __fdiv_rn(e.bias[c], e.scale) : 0.0f;
             ninv[nt][i >> 1][i & 1] = __fmul_rn(__fmul_rn(e.bn_inv ? e.bn_inv[c] : 1.0f, e.scale), cfold);
             nshift[nt][i >> 1][i & 1] = __fmul_rn(e.bn_inv ? e.bn_shift[c] : 0.0f, cfold);
+        }
+    float fa[NT][4];                                   // folded epilogue (k_conv_strip): slope and accumulator offset
+    v4i binit[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = nbase + 4 * NT * kq + 4 * nt + i;
+            fa[nt][i] = FOLD ? e.fold_a[c] : 0.0f;
+            binit[nt][i] = FOLD ? e.fold_b[c] : 0;
         }
     constexpr float kMagic = 12582920.0f;
     constexpr int kMagicBits = 0x4B400008;
@@ -413,7 +503,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
             load_rows(nxt);                            // the three input rows of the next output row
             v4i acc[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = v4i{0, 0, 0, 0};
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = binit[nt];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -423,6 +513,16 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
                     for (int nt = 0; nt < NT; ++nt)
                         acc[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[dy][st][nt], xo, acc[nt], 0, 0, 0);
                 }
+            if constexpr (FOLD) {
+                uint32_t tp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tp[j] = qnn_fold_pair(acc[0][j], acc[1][j], fa[0][j], fa[1][j]);   // (c_j, c_j+4)
+                const uint32_t uo = __builtin_amdgcn_perm(tp[3], tp[1], 0x07030501u);
+                const uint32_t ue = __builtin_amdgcn_perm(tp[2], tp[0], 0x07030501u);
+                __builtin_amdgcn_raw_buffer_store_b32((uo & 0xF0F0F0F0u) | ((ue >> 4) & 0x0F0F0F0Fu), yr, ovoff, 0, 0);
+                ovoff += orowb;
+                return;
+            }
             uint32_t field[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -490,12 +590,16 @@ int launch_strip_s2(const MfmaGeom& mg, const EpiArgs& e, const void* x, const u
     long blocks = (ntasks_l + 3) / 4;
     if (blocks > blocks_cap) blocks = blocks_cap;
     const dim3 grid((unsigned)blocks, (unsigned)ny), block(256);
-    if (e.bias)
-        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, true>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+    if (e.fold_a)            // folded epilogue (the bias is inside the fold)
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false, true>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+                           spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
+                           (uint32_t)img_x, (uint32_t)img_y);
+    else if (e.bias)
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, true, false>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
                            spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
                            (uint32_t)img_x, (uint32_t)img_y);
     else
-        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false, false>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
                            spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
                            (uint32_t)img_x, (uint32_t)img_y);
     return 0;
@@ -530,16 +634,19 @@ int launch_strip(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     long blocks = (ntasks + 3) / 4;
     if (blocks > blocks_cap) blocks = blocks_cap;
     const dim3 grid((unsigned)blocks, (unsigned)ny), block(256);
-    const bool bias = e.bias != nullptr;
-#define STRIP_CASE(RES_, BIAS_)                                                                               \
-    if (res == RES_ && bias == BIAS_) {                                                                       \
-        hipLaunchKernelGGL((k_conv_strip<CIN, NT, RES_, BIAS_>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, \
+    const bool bias = e.bias != nullptr && !(e.fold_a != nullptr && res != 2);   // a fold contains the bias
+#define STRIP_CASE(RES_, BIAS_, FOLD_)                                                                        \
+    if (res == RES_ && bias == BIAS_ && fold == FOLD_) {                                                      \
+        hipLaunchKernelGGL((k_conv_strip<CIN, NT, RES_, BIAS_, FOLD_>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, \
                            ntasks, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),   \
                            best_rc, (uint32_t)img_x, (uint32_t)img_y, (uint32_t)img_r);                        \
         return 0;                                                                                             \
     }
-    STRIP_CASE(0, false) STRIP_CASE(0, true) STRIP_CASE(1, false) STRIP_CASE(1, true)
-    STRIP_CASE(2, false) STRIP_CASE(2, true)
+    // folded epilogue: everything behind the accumulator (bias included) is inside the fold's two constants
+    const bool fold = e.fold_a != nullptr && res != 2;
+    STRIP_CASE(0, false, true) STRIP_CASE(1, false, true)
+    STRIP_CASE(0, false, false) STRIP_CASE(0, true, false) STRIP_CASE(1, false, false) STRIP_CASE(1, true, false)
+    STRIP_CASE(2, false, false) STRIP_CASE(2, true, false)
 #undef STRIP_CASE
     return 1;
 }

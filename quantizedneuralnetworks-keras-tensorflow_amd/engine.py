@@ -550,13 +550,18 @@ class ResidualFusedModel:
     float32 torch ops on unpacked tensors.
     """
 
-    def __init__(self, spec, device="cuda", first_layer="exact"):
+    def __init__(self, spec, device="cuda", first_layer="exact", fold=True):
         """first_layer: kernel for float32 images in front of the first (3-channel) conv, as engine.FusedModel:
         "exact" (default) or "image" (float32 bytes / 255 recognised as bytes; domain flag -> check_domain()).  uint8
-        images always take the typed QNN_STORE_U8 entry."""
+        images always take the typed QNN_STORE_U8 entry.
+        fold: True (default) = every int4 -> int4 layer gets its epilogue folded to integer thresholds the first time it
+        runs (qnn_fold_prepare: proven equal to the float32 chain on the layer's whole accumulator domain; layers the
+        library cannot fold exactly keep the chain); False = always the float32 chain.  Same bits either way."""
         if first_layer not in ("exact", "image"):
             raise ValueError("first_layer must be 'exact' or 'image', got %r" % (first_layer,))
         self.first_layer = first_layer
+        self.fold = bool(fold)
+        self._folds = {}                     # (conv, bn, shortcut kind, ...) -> _abi.Fold or None
         self.device = torch.device(device)
         self.spec = spec
         self.names = [op.get("dst", "t%d" % i) for i, op in enumerate(spec)]
@@ -675,8 +680,17 @@ class ResidualFusedModel:
             if self.first_layer == "image" and xs == _abi.STORE_F32 and src is memo["input"]:
                 xs = _abi.STORE_F32_IMAGE        # the images: declared as bytes / 255 for this call (typed entry)
 
+            fold = None
+            if self.fold and xs == _abi.STORE_I4 and out_store == _abi.STORE_I4 and fn == _abi.FN_QUANTIZED_TANH and ab == 4 \
+                    and (res is None or (isinstance(res, _Packed) and res.store == _abi.STORE_I4 and res.bits == 4)):
+                fkey = (ci, bn_i, xb, None if res is None else float(post_scale))
+                if fkey not in self._folds:
+                    self._folds[fkey] = _abi.Fold.try_prepare(
+                        w, xs, xb, inv, shift, fn, ab, out_store, **{k: v for k, v in rkw.items()})
+                fold = self._folds[fkey]
+
             def launch():
-                return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, **rkw)
+                return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, fold=fold, **rkw)
 
             y, Ho, Wo = launch()
             if self.kernel_log is not None:

@@ -1,0 +1,176 @@
+"""The epilogue as integer thresholds (include/qnn_abi.h, qnn_fold_prepare; csrc/qnn_fold.h).
+
+What the reference computes behind a low-bit convolution -- K.bias_add, BatchNormalization (models/vgg.py:16,
+models/resnet.py:61), the residual merge keras.layers.add + Lambda(x * 0.5) (models/resnet.py:127-128) and quantized_tanh
+(quantized_ops.py:87-100) -- is a step function of the integer accumulator.  These tests
+
+  * sweep the WHOLE accumulator domain of a layer (x all 16 shortcut codes), channel by channel, through the folded
+    epilogue (qnn_fold_eval: the device function the kernels inline) against the oracle's float32 restatement of the
+    chain (bias_add, batchnorm_inference, add, scale, quantized_tanh);
+  * run the strip kernels with and without the fold on the same tensors: identical bits, and the oracle's;
+  * run the residual engine both ways on whole networks.
+"""
+import numpy as np
+import pytest
+import torch
+
+from qnn_amd import _abi, engine, nets
+from oracle import qnn_oracle as O
+from test_gpu_parity import dev, host, Q, _rand_bn
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _layer(rng, cin, cout, k=3, bias=True, stride=1, gamma_sign=None):
+    op = {"op": "conv", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (k, k, cin, cout)).astype(F32),
+          "bias": (rng.standard_normal(cout) * 0.05).astype(F32) if bias else None, "strides": (stride, stride),
+          "padding": "same"}
+    bn = _rand_bn(rng, cout, k * k * cin * 0.12)
+    if gamma_sign is not None:
+        bn["gamma"] = (np.abs(bn["gamma"]) * gamma_sign).astype(F32)
+    return op, bn
+
+
+def _chain_codes(acc, sc, c, op, bn, x_bits=4):
+    """The reference chain on integer accumulators of channel c (float32, one rounding per operation): conv value =
+    acc * 2^-(wshift + xshift) (exact), K.bias_add, BatchNormalization, [(shortcut + y) * 0.5], quantized_tanh(nb=4)."""
+    v = (acc.astype(F32) * F32(2.0 ** -(3 + x_bits - 1))).astype(F32)
+    if op["bias"] is not None:
+        v = O.bias_add(v, op["bias"][c])
+    v = O.batchnorm_inference(v, bn["gamma"][c], bn["beta"][c], bn["mean"][c], bn["var"][c], bn["eps"])
+    if sc is not None:
+        r = (sc.astype(F32) * F32(0.125)).astype(F32)
+        v = ((r + v).astype(F32) * F32(0.5)).astype(F32)
+    return np.rint(O.quantized_tanh(v, 4) * F32(8)).astype(np.int32)
+
+
+def _prep(op, bn, res, x_bits=4):
+    w = engine._prepack(op, _abi.STORE_I4, torch.device("cuda"), stride=op["strides"][0], same_pad=True)
+    i, s = engine.bn_constants(bn)
+    inv, shift = dev(i), dev(s)
+    kw = {}
+    if res:
+        kw = dict(res=torch.zeros(1, dtype=torch.int32, device="cuda"), res_store=_abi.STORE_I4, res_bits=4, post_scale=0.5)
+    f = _abi.Fold.try_prepare(w, _abi.STORE_I4, x_bits, inv, shift, _abi.FN_QUANTIZED_TANH, 4, _abi.STORE_I4, **kw)
+    return w, inv, shift, f
+
+
+@pytest.mark.parametrize("cin,cout,k,bias,res", [(16, 16, 3, False, False), (16, 16, 3, False, True), (16, 32, 3, True, False),
+                                                 (32, 32, 3, True, True), (64, 64, 3, False, True), (64, 64, 3, False, False),
+                                                 (64, 64, 1, False, False)])
+def test_whole_accumulator_domain_per_channel(cin, cout, k, bias, res):
+    """Every accumulator value the layer can produce (from its quantized weights and the 4-bit input codes), for every
+    channel and -- with a shortcut -- every shortcut code: folded epilogue == oracle chain.  Both signs of the BN scale."""
+    rng = np.random.default_rng(cin * 100 + cout + k + 7 * bias + 13 * res)
+    op, bn = _layer(rng, cin, cout, k, bias)
+    w, inv, shift, f = _prep(op, bn, res)
+    assert f is not None
+    wc, wshift = O.weight_codes(op)                     # HWIO integer codes
+    assert wshift == 3
+    wc = wc.reshape(-1, cout)
+    hi = np.maximum(wc * -8, wc * 7).sum(axis=0)
+    lo = np.minimum(wc * -8, wc * 7).sum(axis=0)
+    assert f.acc_lo == lo.min() and f.acc_hi == hi.max(), (f.acc_lo, f.acc_hi, lo.min(), hi.max())
+    assert f.shortcut_codes == (16 if res else 1)
+    A, beta = (host(t) for t in f.constants("cuda"))
+    folded = A != 0
+    assert folded.sum() == f.folded
+    assert f.points == int(((hi - lo + 1)[folded] * (16 if res else 1)).sum())
+    # the search must succeed almost everywhere: a fold that fails is a performance bug, never a correctness one
+    assert f.folded >= cout - max(1, cout // 8), (f.folded, cout)
+    checked = 0
+    for c in np.nonzero(folded)[0]:
+        acc = np.arange(lo[c], hi[c] + 1, dtype=np.int32)
+        for sc in (range(-8, 8) if res else (None,)):
+            scv = None if sc is None else np.full_like(acc, sc)
+            got = host(f.eval(int(c), dev(acc), None if scv is None else dev(scv)))
+            want = _chain_codes(acc, scv, c, op, bn)
+            np.testing.assert_array_equal(got, want, err_msg="channel %d shortcut %r" % (c, sc))
+            checked += acc.size
+    assert checked == f.points
+    print("[fold] %dx%d k%d res=%d: %d / %d channels folded, %d points swept against the oracle"
+          % (cin, cout, k, res, f.folded, cout, checked))
+
+
+def _packed_codes(rng, n, h, w_, c):
+    pre = rng.standard_normal((n, h, w_, c)).astype(F32)
+    x = O.run_spec([Q(4)], pre)
+    return x, _abi.pack(dev(x), c, _abi.FN_GRID, 4, _abi.STORE_I4)
+
+
+@pytest.mark.parametrize("cin,cout,hw,n,stride", [(16, 16, (20, 32), 3, 1), (16, 16, (33, 23), 2, 1), (32, 32, (9, 16), 5, 1),
+                                                  (64, 64, (14, 14), 3, 1), (64, 128, (5, 23), 2, 1), (16, 32, (16, 16), 2, 2),
+                                                  (32, 64, (7, 9), 2, 2), (16, 16, (224, 224), 1, 1)])
+@pytest.mark.parametrize("gamma_sign", [None, 1.0, -1.0])
+def test_strip_kernels_with_and_without_the_fold(cin, cout, hw, n, stride, gamma_sign):
+    """k_conv_strip / k_conv_strip_s2 with the folded epilogue: the same bits as the float32 chain and as the oracle, with
+    and without the residual merge, ragged strips, every border class."""
+    rng = np.random.default_rng(cin + 3 * cout + hw[0] + stride)
+    H, W = hw
+    x, xp = _packed_codes(rng, n, H, W, cin)
+    for bias in (False, True):
+        op, bn = _layer(rng, cin, cout, 3, bias, stride, gamma_sign)
+        for res in ((False, True) if stride == 1 else (False,)):
+            w, inv, shift, f = _prep(op, bn, res)
+            assert f is not None
+            Ho, Wo = -(-H // stride), -(-W // stride)
+            kw = {}
+            sc = None
+            if res:
+                sc, scp = _packed_codes(rng, n, Ho, Wo, cout)
+                kw = dict(res=scp, res_store=_abi.STORE_I4, res_bits=4, post_scale=0.5)
+            outs = []
+            for fold in (None, f):
+                y, _, _ = _abi.conv2d(w, xp, _abi.STORE_I4, 4, n, H, W, inv, shift, _abi.FN_QUANTIZED_TANH, 4, 1,
+                                      _abi.STORE_I4, fold=fold, **kw)
+                assert _abi.last_kernel() == ("strip_i4_c%d_s2" % cin if stride == 2 else "strip_i4_c%d" % cin)
+                outs.append(host(_abi.unpack(y, n * Ho * Wo, cout, _abi.STORE_I4, 4)).reshape(n, Ho, Wo, cout))
+            np.testing.assert_array_equal(outs[1], outs[0])
+            v = O.quantized_conv2d_call(x, op["kernel"], op["bias"], nb=4, strides=op["strides"])
+            v = O.batchnorm_inference(v, bn["gamma"], bn["beta"], bn["mean"], bn["var"], bn["eps"])
+            if res:
+                v = ((sc + v).astype(F32) * F32(0.5)).astype(F32)
+            np.testing.assert_array_equal(outs[1], O.quantized_tanh(v, 4))
+            assert f.usable or f.folded < cout
+
+
+def test_fold_handle_is_bound_to_its_layer_and_epilogue():
+    """A fold prepared for one layer / BN / shortcut form is rejected (QNN_EINVAL) anywhere else; unsupported forms
+    (other bit widths, float32 shortcut) fold nothing (None) and the call without a fold still works."""
+    rng = np.random.default_rng(3)
+    op, bn = _layer(rng, 16, 16)
+    op2, bn2 = _layer(rng, 16, 16)
+    w, inv, shift, f = _prep(op, bn, False)
+    w2, inv2, shift2, f2 = _prep(op2, bn2, True)
+    x, xp = _packed_codes(rng, 1, 8, 16, 16)
+    args = (_abi.STORE_I4, 4, 1, 8, 16)
+    with pytest.raises(_abi.QnnError, match="fold handle was prepared for another"):
+        _abi.conv2d(w2, xp, *args, inv2, shift2, _abi.FN_QUANTIZED_TANH, 4, 1, _abi.STORE_I4, fold=f)
+    with pytest.raises(_abi.QnnError, match="fold handle was prepared for another"):
+        _abi.conv2d(w, xp, *args, inv2, shift2, _abi.FN_QUANTIZED_TANH, 4, 1, _abi.STORE_I4, fold=f)
+    with pytest.raises(_abi.QnnError, match="fold handle was prepared for another"):      # prepared WITH a shortcut
+        _abi.conv2d(w2, xp, *args, inv2, shift2, _abi.FN_QUANTIZED_TANH, 4, 1, _abi.STORE_I4, fold=f2)
+    assert _abi.Fold.try_prepare(w, _abi.STORE_I4, 4, inv, shift, _abi.FN_QUANTIZED_TANH, 3, _abi.STORE_I4) is None
+    assert _abi.Fold.try_prepare(w, _abi.STORE_I4, 4, inv, shift, _abi.FN_BINARY_TANH, 0, _abi.STORE_I4) is None
+    assert _abi.Fold.try_prepare(w, _abi.STORE_I4, 4, inv, shift, _abi.FN_QUANTIZED_TANH, 4, _abi.STORE_I4,
+                                 res=torch.zeros(4, device="cuda"), res_store=_abi.STORE_F32, post_scale=0.5) is None
+
+
+@pytest.mark.parametrize("nres", [1, 2])
+def test_residual_engine_with_and_without_folds(nres):
+    """Whole CIFAR ResNets (models/resnet.py) through engine.ResidualFusedModel: folds on (default) and off give the
+    oracle's logits bit for bit, and the folds were actually used."""
+    cf = nets.Config(network_type="full-qnn", wbits=4, abits=4, architecture="RESNET", nres=nres, dim=32)
+    spec = nets.build_spec(cf, 5)[:-1]
+    x = nets.synthetic_images(cf, 3, 5)
+    want = O.run_spec(spec, x, float_conv="device")
+    m = engine.ResidualFusedModel(spec)
+    got = host(m(dev(x)))
+    np.testing.assert_array_equal(got, want)
+    folds = [f for f in m._folds.values() if f is not None]
+    assert len(folds) >= 6 * nres - 2 and sum(f.usable for f in folds) >= len(folds) - 2, \
+        [(f.folded, f.channels) for f in folds]
+    m0 = engine.ResidualFusedModel(spec, fold=False)
+    np.testing.assert_array_equal(host(m0(dev(x))), want)
+    assert not m0._folds

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time ONE packed 3x3 (or 1x1) int4/int8 conv layer with a fused BN + quantized_tanh epilogue, as the fused engines
 launch it.  Usage:  tools/bench_conv.py N H W CIN COUT [k=3] [stride=1] [bits=4] [res=0|1] [opt=key:val,...] [out=i4|f32]
-[store=4|8 (packed storage of the codes; 8 = `bits`-bit codes kept in bytes)] [pool=1|2]
+[store=4|8 (packed storage of the codes; 8 = `bits`-bit codes kept in bytes)] [pool=1|2] [fold=0|1 (qnn_fold_prepare)]
 Prints one JSON line per call: kernel tag, us, pixels/us, fraction of the 8 TB/s HBM roof on in + out (+ shortcut)."""
 import importlib
 import json
@@ -43,9 +43,16 @@ def main():
         r = abi.pack(torch.randn((N, Ho, Wo, cout), device="cuda"), cout, abi.FN_QUANTIZED_TANH, bits, store)
         rkw = dict(res=r, res_store=store, res_bits=bits, post_scale=0.5)
 
+    fold = None
+    if int(kw.get("fold", 0)):
+        inv = torch.as_tensor(rng.uniform(0.02, 0.08, cout).astype(np.float32)).cuda()
+        shift = torch.as_tensor((rng.standard_normal(cout) * 0.5).astype(np.float32)).cuda()
+        fold = abi.Fold.try_prepare(w, store, bits, inv, shift, fn, bits, out_store, **rkw)
+        assert fold is not None and fold.usable, (fold and (fold.folded, fold.channels))
+
     def launch():
         return abi.conv2d(w, xp, store, bits, N, H, W, inv if out == "i4" else None, shift if out == "i4" else None,
-                          fn, bits if out == "i4" else 0, pool, out_store, **rkw)[0]
+                          fn, bits if out == "i4" else 0, pool, out_store, fold=fold, **rkw)[0]
 
     for _ in range(5):
         launch()
@@ -66,7 +73,7 @@ def main():
     out_b = N * (Ho // pool) * (Wo // pool) * cout * (sb / 8 if out == "i4" else 4)
     tot = in_b + out_b * (2 if res else 1)
     print(json.dumps({"kernel": abi.last_kernel(), "shape": [N, H, W, cin, cout, k, stride], "res": res, "out": out, "store": store, "pool": pool,
-                      "opt": kw.get("opt", ""), "us": round(best * 1e3, 2),
+                      "opt": kw.get("opt", ""), "fold": int(kw.get("fold", 0)), "us": round(best * 1e3, 2),
                       "Mpix_per_s": round(N * Ho * Wo / best / 1e3, 1),
                       "TMACps": round(N * Ho * Wo * k * k * cin * cout / best / 1e9, 1),
                       "hbm_frac": round(tot / best / 1e6 / 8000.0, 3)}))
