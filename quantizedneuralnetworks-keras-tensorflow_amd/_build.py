@@ -18,7 +18,7 @@ LIB = os.path.join(CSRC, "libqnn_hip.so")
 STAMP = os.path.join(CSRC, "libqnn_hip.srchash")
 OBJDIR = os.path.join(CSRC, "build")
 SOURCES = ["qnn_api.hip", "qnn_elementwise.hip", "qnn_conv.hip", "qnn_mfma.hip", "qnn_mfma_areg.hip",
-           "qnn_mfma_small.hip", "qnn_mfma_strip.hip", "qnn_first.hip", "qnn_first_fixed.hip", "qnn_first_u8.hip", "qnn_stem.hip", "qnn_fold.hip"]
+           "qnn_mfma_small.hip", "qnn_mfma_strip.hip", "qnn_mfma_strip16.hip", "qnn_first.hip", "qnn_first_fixed.hip", "qnn_first_u8.hip", "qnn_stem.hip", "qnn_fold.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-Wno-cuda-compat",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]

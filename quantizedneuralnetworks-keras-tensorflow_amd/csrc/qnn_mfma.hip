@@ -833,6 +833,13 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                 ms.x_bytes = 0; ms.w_bytes = (uint32_t)wb_; ms.ablate = 0;
                 EpiArgs es = e;
                 es.scale = e.scale * (1.0f / 256.0f);        // both operands carry *16
+                // 16 -> 16 channels with a usable fold and an even width: the LDS-staged form (qnn_mfma_strip16.hip: a sixth
+                // of the load and a quarter of the store instructions)
+                static const bool lds16_off = QNN_ENV_STR("QNN_STRIP16_LDS_OFF") != nullptr;   // A/B switch (experiment builds only)
+                if (g.cin == 16 && !lds16_off && qnn_launch_strip16_lds(ms, es, x, w->d_mfma, y, s) == 0) {
+                    snprintf(name, name_len, "strip_i4_c16_lds");
+                    return 0;
+                }
                 snprintf(name, name_len, g.stride == 2 ? "strip_i4_c%d_s2" : "strip_i4_c%d", g.cin);
                 if (qnn_launch_strip(g.cin, ms, es, x, w->d_mfma, y, s) == 0) return 0;
             }

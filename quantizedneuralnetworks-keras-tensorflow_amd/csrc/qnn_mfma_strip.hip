@@ -46,7 +46,7 @@
 #define QNN_STRIP64_WPS 2        // Cin 64 (two 32-channel halves per strip): 164-200 VGPRs, spills at 3 per SIMD
 #endif
 #ifndef QNN_STRIP16_DEPTH
-#define QNN_STRIP16_DEPTH 6      // input rows requested ahead of the row being computed (see the ring in k_conv_strip)
+#define QNN_STRIP16_DEPTH 3      // input rows requested ahead of the row being computed (see the ring in k_conv_strip)
 #endif
 #ifndef QNN_STRIP32_DEPTH
 #define QNN_STRIP32_DEPTH 3
@@ -212,7 +212,12 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
         uint2 raw[D][ST];
         uint32_t rs[D][NT];                            // packed shortcut: [.][0] holds the lane's whole 2*NT-byte field
         float4 rf[D][NT];
+        int abl_st = 0; uint32_t abl_acc = 0;
+        int abl_rows = 0;                              // timing experiments only (QNN_STRIP_ABL, -DQNN_EXPERIMENTS builds)
         auto load_row = [&](uint2 (&dst)[ST]) {
+#ifdef QNN_STRIP_ABL
+            if ((QNN_STRIP_ABL & 2) && ++abl_rows > D + 2) return;              // 2: no input loads behind the preamble
+#endif
 #pragma unroll
             for (int st = 0; st < ST; ++st) {
                 dst[st] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xr, voff[st], 0, 0));
@@ -289,6 +294,13 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
                     }
                     const uint32_t mm = (po & 0xF000F000u) | ((pe >> 4) & ~0xF000F000u);          // v_bfi_b32: bytes 1, 3 = (c1:c0), (c3:c2)
                     const uint32_t o16 = __builtin_amdgcn_perm(0u, mm, 0x0C0C0301u);
+#ifdef QNN_STRIP_ABL
+                    if (QNN_STRIP_ABL & 1) {                                   // 1: one store per eight rows (results wrong)
+                        static_assert(true, "");
+                        abl_acc ^= o16;
+                        if ((++abl_st & 7) == 0) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)abl_acc, yr, ovoff, 0, 0);
+                    } else
+#endif
                     __builtin_amdgcn_raw_buffer_store_b16((unsigned short)o16, yr, ovoff, 0, 0);
                 } else {
                     static_assert(NT <= 2, "a lane's fields must fit one word");

@@ -101,7 +101,9 @@ def _packed_codes(rng, n, h, w_, c):
 
 @pytest.mark.parametrize("cin,cout,hw,n,stride", [(16, 16, (20, 32), 3, 1), (16, 16, (33, 23), 2, 1), (32, 32, (9, 16), 5, 1),
                                                   (64, 64, (14, 14), 3, 1), (64, 128, (5, 23), 2, 1), (16, 32, (16, 16), 2, 2),
-                                                  (32, 64, (7, 9), 2, 2), (16, 16, (224, 224), 1, 1)])
+                                                  (32, 64, (7, 9), 2, 2), (16, 16, (224, 224), 1, 1), (16, 16, (1, 2), 2, 1),
+                                                  (16, 16, (3, 18), 3, 1), (16, 16, (13, 50), 70, 1), (16, 16, (40, 16), 2, 1),
+                                                  (16, 16, (25, 34), 400, 1)])
 @pytest.mark.parametrize("gamma_sign", [None, 1.0, -1.0])
 def test_strip_kernels_with_and_without_the_fold(cin, cout, hw, n, stride, gamma_sign):
     """k_conv_strip / k_conv_strip_s2 with the folded epilogue: the same bits as the float32 chain and as the oracle, with
@@ -124,7 +126,10 @@ def test_strip_kernels_with_and_without_the_fold(cin, cout, hw, n, stride, gamma
             for fold in (None, f):
                 y, _, _ = _abi.conv2d(w, xp, _abi.STORE_I4, 4, n, H, W, inv, shift, _abi.FN_QUANTIZED_TANH, 4, 1,
                                       _abi.STORE_I4, fold=fold, **kw)
-                assert _abi.last_kernel() == ("strip_i4_c%d_s2" % cin if stride == 2 else "strip_i4_c%d" % cin)
+                want_kernel = "strip_i4_c%d_s2" % cin if stride == 2 else "strip_i4_c%d" % cin
+                if fold is not None and fold.usable and (cin, cout, stride) == (16, 16, 1) and W % 2 == 0:
+                    want_kernel = "strip_i4_c16_lds"         # the LDS-staged form of the 16-channel stage (qnn_mfma_strip16.hip)
+                assert _abi.last_kernel() == want_kernel, (_abi.last_kernel(), want_kernel)
                 outs.append(host(_abi.unpack(y, n * Ho * Wo, cout, _abi.STORE_I4, 4)).reshape(n, Ho, Wo, cout))
             np.testing.assert_array_equal(outs[1], outs[0])
             v = O.quantized_conv2d_call(x, op["kernel"], op["bias"], nb=4, strides=op["strides"])

@@ -11,8 +11,10 @@ F32 = np.float32
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(0)
 out = []
-for (n, hw, cin, cout, stride) in [(64, 224, 16, 16, 1), (64, 112, 32, 32, 1), (64, 56, 64, 64, 1), (64, 224, 16, 32, 2),
-                                   (64, 112, 32, 64, 2)]:
+SHAPES = [(64, 224, 16, 16, 1), (64, 112, 32, 32, 1), (64, 56, 64, 64, 1), (64, 224, 16, 32, 2), (64, 112, 32, 64, 2)]
+if os.environ.get("NS"):        # batch-size sweep of the 16-channel stage: fixed cost per launch vs cost per image
+    SHAPES = [(int(v), 224, 16, 16, 1) for v in os.environ["NS"].split(",")]
+for (n, hw, cin, cout, stride) in SHAPES:
     op = {"op": "conv", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (3, 3, cin, cout)).astype(F32),
           "bias": None, "strides": (stride, stride), "padding": "same"}
     var = 9 * cin * 0.12
