@@ -252,7 +252,10 @@ int qnn_weights_check(const qnn_weights_t* w, void* stream);
  *     code = sat16( 2 * sat16( round((acc*256 + beta[c]) * A[c] * 32767) + (sc + 8) * 1024 ) ) >> 12     (shortcut code sc)
  * (v_cvt_f32_i32, v_mul_f32, v_cvt_pknorm_i16_f32, v_pk_add_i16 clamp: 3 to 5 vector instructions per value instead
  * of 6 to 10) reproduces the chain's code on every point.  The offset costs nothing: it is the initial value of the
- * MFMA accumulator.  A fold is accepted only if the exhaustive comparison finds no differing point; otherwise the
+ * MFMA accumulator.  Where it also reproduces the chain on the whole domain, the "bits" form is used instead
+ * (mode 2; exact while |acc*256 + beta| < 2^22, monotone and saturating beyond): the stored offset carries 0x4B400000, the accumulator is then the bit pattern of the float
+ * 12582912 + acc*256 + beta, and round(...) is taken of fma(that float, A[c], C[c]) with C = float(-12582912 A): one
+ * v_fma_f32 in place of the conversion and the multiply.  A fold is accepted only if the exhaustive comparison finds no differing point; otherwise the
  * handle is marked "not folded" and the kernels keep evaluating the float32 chain -- results are bit-identical either
  * way, which is what the sweep proves.
  *
@@ -274,10 +277,12 @@ typedef struct qnn_fold_info {
     int32_t shortcut_codes;  /* 16 with a shortcut, else 1                                            */
     int64_t points;          /* (accumulator, shortcut) points compared, summed over the channels      */
     int32_t acc_lo, acc_hi;  /* union of the channels' accumulator domains (true integer units)        */
+    int32_t mode;            /* 1: conversion + multiply; 2: "bits" (the accumulator carries the float's bit pattern) */
 } qnn_fold_info_t;
 int qnn_fold_info(const qnn_fold_t* f, qnn_fold_info_t* info);
-/* DEVICE copies of A[cout] (float32) and beta[cout] (int32) -- tests and diagnostics */
-int qnn_fold_constants(const qnn_fold_t* f, float* A, int32_t* beta, void* stream);
+/* DEVICE copies of A[cout] (float32), beta[cout] (int32; mode 2: + 0x4B400000) and, if C != NULL, C[cout] (float32) --
+ * tests and diagnostics */
+int qnn_fold_constants(const qnn_fold_t* f, float* A, int32_t* beta, float* C, void* stream);
 /* Evaluate the FOLDED epilogue (the very device function the kernels inline) for channel `c` on n accumulator values
  * acc[i] (true integer units, DEVICE int32) and, with a shortcut, shortcut codes sc[i] (DEVICE int32, else NULL):
  * codes[i] (DEVICE int32) = the 4-bit output code.  Lets a test sweep the whole domain against an independent

@@ -43,7 +43,7 @@ class Epilogue(ctypes.Structure):
 class FoldInfo(ctypes.Structure):
     _fields_ = [("channels", ctypes.c_int32), ("folded", ctypes.c_int32), ("usable", ctypes.c_int32),
                 ("shortcut_codes", ctypes.c_int32), ("points", ctypes.c_int64),
-                ("acc_lo", ctypes.c_int32), ("acc_hi", ctypes.c_int32)]
+                ("acc_lo", ctypes.c_int32), ("acc_hi", ctypes.c_int32), ("mode", ctypes.c_int32)]
 
 
 class QnnError(RuntimeError):
@@ -107,7 +107,7 @@ def load():
     lib.qnn_fold_prepare.argtypes = [vp, ci, ci, ctypes.POINTER(Epilogue), vp, ctypes.POINTER(vp)]
     lib.qnn_fold_free.argtypes = [vp]
     lib.qnn_fold_info.argtypes = [vp, ctypes.POINTER(FoldInfo)]
-    lib.qnn_fold_constants.argtypes = [vp, vp, vp, vp]
+    lib.qnn_fold_constants.argtypes = [vp, vp, vp, vp, vp]
     lib.qnn_fold_eval.argtypes = [vp, ci, vp, vp, vp, sz, vp]
     lib.qnn_conv2d_workspace_bytes.argtypes = [vp, ci, ci, ci]
     lib.qnn_conv2d_workspace_bytes.restype = sz
@@ -325,7 +325,7 @@ class Fold:
         check(load().qnn_fold_info(self.handle, ctypes.byref(info)), "qnn_fold_info")
         self.channels, self.folded, self.usable = info.channels, info.folded, bool(info.usable)
         self.points, self.acc_lo, self.acc_hi = info.points, info.acc_lo, info.acc_hi
-        self.shortcut_codes = info.shortcut_codes
+        self.shortcut_codes, self.mode = info.shortcut_codes, info.mode
 
     @classmethod
     def try_prepare(cls, *a, **kw):
@@ -335,7 +335,7 @@ class Fold:
     def constants(self, device):
         A = torch.empty(self.channels, dtype=torch.float32, device=device)
         b = torch.empty(self.channels, dtype=torch.int32, device=device)
-        check(load().qnn_fold_constants(self.handle, ptr(A), ptr(b), stream_ptr()), "qnn_fold_constants")
+        check(load().qnn_fold_constants(self.handle, ptr(A), ptr(b), None, stream_ptr()), "qnn_fold_constants")
         return A, b
 
     def eval(self, c, acc, sc=None):

@@ -1138,6 +1138,7 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
     e->trick_s = epi->trick_s;
     e->fold_a = nullptr;
     e->fold_b = nullptr;
+    e->fold_c = nullptr;
     if (epi->fold) {
         // the fold must have been prepared for exactly this layer and epilogue; a handle whose sweep found a differing
         // point on some channel (folded < cout) is accepted and ignored: the kernels evaluate the float32 chain
@@ -1150,7 +1151,7 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
                                       f->post_scale == epi->post_scale)) &&
                         epi->trick_s == 0.0f,
                     QNN_EINVAL, "epilogue: the fold handle was prepared for another layer / epilogue (qnn_fold_prepare)");
-        if (f->folded == f->cout) { e->fold_a = f->d_a; e->fold_b = f->d_b; }
+        if (f->folded == f->cout) { e->fold_a = f->d_a; e->fold_b = f->d_b; e->fold_c = f->mode == 2 ? f->d_c : nullptr; }
     }
     QNN_REQUIRE(epi->trick_s == 0.0f || (epi->trick_s > 0.0f && epi->trick_s < 1.0e6f), QNN_EINVAL,
                 "epilogue: trick_s=%g (the layer's kernel_lr_multiplier, or 0)", (double)epi->trick_s);

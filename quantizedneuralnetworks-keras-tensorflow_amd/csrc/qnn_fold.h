@@ -12,16 +12,35 @@
 //   shortcut sc:   T is Q11;  W = sat16(T + (sc + 8) * 1024);  T' = sat16(W + W)   two v_pk_add_i16 clamp per pair
 //     code = T >> 12 (arithmetic): the top nibble of each 16-bit half IS the two's-complement code.
 // Pairs of values live in the two halves of one register from the conversion on.
+//
+// Second form ("bits", mode 2; tried first by qnn_fold_prepare -- it needs the thresholds, not the whole domain, inside
+// |accw + beta| < 2^22: beyond that the bit pattern leaves the constant's binade, which keeps the order and only saturates): the stored
+// offset is beta + 0x4B400000, so the integer accumulator IS the bit pattern of the float 12582912 + (accw + beta), and
+//     u = fma(as_float(acc), A, C),   C = float(-12582912 * A)                    one v_fma_f32, no conversion
+// replaces the conversion and the multiply (the residue 12582912 * A + C is a constant the offset search absorbs).
 #pragma once
 #include "qnn_common.h"
 
 #ifdef __HIPCC__
 typedef short qnn_s2 __attribute__((ext_vector_type(2)));
 
+constexpr int kFoldMagicBits = 0x4B400000;          // float bits of 12582912 = 1.5 * 2^23 (ulp 1)
+constexpr double kFoldMagic = 12582912.0;
+
 // two accumulators (offset included) -> two saturated Q12 (no shortcut) / Q11 (shortcut) values
 __device__ __forceinline__ uint32_t qnn_fold_pair(int accw0, int accw1, float a0, float a1) {
     const float u0 = __fmul_rn((float)accw0, a0), u1 = __fmul_rn((float)accw1, a1);
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(u0, u1));
+}
+// the same on accumulators that carry the magic constant ("bits" form)
+__device__ __forceinline__ uint32_t qnn_fold_pair_bits(int acc0, int acc1, float a0, float a1, float c0, float c1) {
+    const float u0 = __fmaf_rn(__int_as_float(acc0), a0, c0), u1 = __fmaf_rn(__int_as_float(acc1), a1, c1);
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(u0, u1));
+}
+template <int MODE>
+__device__ __forceinline__ uint32_t qnn_fold_pair_m(int acc0, int acc1, float a0, float a1, float c0, float c1) {
+    if constexpr (MODE == 2) return qnn_fold_pair_bits(acc0, acc1, a0, a1, c0, c1);
+    else return qnn_fold_pair(acc0, acc1, a0, a1);
 }
 // shortcut merge: s = ((sc + 8) << 10) in both halves (offset-coded shortcut codes at Q11 / 2)
 __device__ __forceinline__ uint32_t qnn_fold_merge(uint32_t t, uint32_t s) {
@@ -31,9 +50,9 @@ __device__ __forceinline__ uint32_t qnn_fold_merge(uint32_t t, uint32_t s) {
 // the 4-bit codes of a pair (tests / verifier; the kernels pick the nibbles up with v_perm_b32 / v_bfi_b32)
 __device__ __forceinline__ int qnn_fold_code_lo(uint32_t t) { return (int)(short)(t & 0xFFFFu) >> 12; }
 __device__ __forceinline__ int qnn_fold_code_hi(uint32_t t) { return (int)t >> 28; }
-// one value, both forms (sc ignored without a shortcut)
-__device__ __forceinline__ int qnn_fold_code(int accw, float a, bool res, int sc) {
-    uint32_t t = qnn_fold_pair(accw, accw, a, a);
+// one value: accw = accumulator + stored offset; mode 1 (conversion + multiply) or 2 (bits); sc ignored without a shortcut
+__device__ __forceinline__ int qnn_fold_code(int accw, float a, float c, int mode, bool res, int sc) {
+    uint32_t t = mode == 2 ? qnn_fold_pair_bits(accw, accw, a, a, c, c) : qnn_fold_pair(accw, accw, a, a);
     if (res) t = qnn_fold_merge(t, (uint32_t)((sc + 8) << 10) * 0x00010001u);
     return qnn_fold_code_lo(t);
 }
@@ -49,8 +68,10 @@ struct qnn_fold {
     int has_res, res_store, res_bits;
     float post_scale;
     int cout;
+    int mode;                      // 1: u = float(accw + beta) * A;  2 ("bits"): u = fma(as_float(accw + beta'), A, C)
     float* d_a;                    // [cout] slope
-    int32_t* d_b;                  // [cout] offset, units of acc / 256
+    int32_t* d_b;                  // [cout] offset, units of acc / 256 (mode 2: + 0x4B400000)
+    float* d_c;                    // [cout] mode 2: C = float(-12582912 * A); mode 1: zeros
     int folded;                    // channels whose fold reproduced the chain on the whole domain
     long long points;
     int acc_lo, acc_hi;

@@ -34,8 +34,10 @@ struct FoldProblem {
     int a_lo, a_hi;                  // range of the input codes
     int has_res;
     float res_scale, post_scale;     // shortcut value = code * res_scale; merged = (shortcut + y) * post_scale
+    int mode;                        // 1 or 2 (qnn_fold.h)
     float* A;
     int32_t* beta;
+    float* C;
     int32_t* status;                 // per channel: 1 folded, 0 not
     int32_t* dom;                    // per channel: lo, hi
     unsigned long long* points;      // per channel: points compared
@@ -90,7 +92,9 @@ __global__ __launch_bounds__(kThreads) void k_fold_prepare(FoldProblem p) {
     }
     lo = block_sum(lo, sh);
     hi = block_sum(hi, sh);
-    if (t == 0) { p.dom[2 * c] = (int)lo; p.dom[2 * c + 1] = (int)hi; p.status[c] = 0; p.A[c] = 0.0f; p.beta[c] = 0; p.points[c] = 0; }
+    if (t == 0) { p.dom[2 * c] = (int)lo; p.dom[2 * c + 1] = (int)hi; p.status[c] = 0; p.A[c] = 0.0f; p.beta[c] = 0; p.C[c] = 0.0f; p.points[c] = 0; }
+    const int mode = p.mode;
+    const int magic = mode == 2 ? kFoldMagicBits : 0;
     // ---- real-number constants of the chain ----
     const double inv = p.e.bn_inv ? (double)p.e.bn_inv[c] : 1.0, shift = p.e.bn_inv ? (double)p.e.bn_shift[c] : 0.0;
     const double bias = p.e.bias ? (double)p.e.bias[c] : 0.0;
@@ -127,19 +131,20 @@ __global__ __launch_bounds__(kThreads) void k_fold_prepare(FoldProblem p) {
         const int step = cand == 0 ? 0 : ((cand & 1) ? (cand + 1) / 2 : -(cand / 2));
         float A = (float)a_nom;
         A = __int_as_float(__float_as_int(A) + step);                          // float32 neighbours (same sign, same binade nearly always)
+        const float C = mode == 2 ? (float)(-kFoldMagic * (double)A) : 0.0f;
         const bool res = p.has_res != 0;
         // folded thresholds in the z domain: accw = dir * z'
         long long blo = -kInf, bhi = kInf;
         if (active) {
             const long long Zlo = 256 * zlo + bnz - (1 << 20), Zhi = 256 * zhi + bnz + (1 << 20);
             long long X;
-            if (qnn_fold_code((int)(dir * Zhi), A, res, sc) < k) X = kInf;
-            else if (qnn_fold_code((int)(dir * Zlo), A, res, sc) >= k) X = -kInf;
+            if (qnn_fold_code((int)(dir * Zhi) + magic, A, C, mode, res, sc) < k) X = kInf;
+            else if (qnn_fold_code((int)(dir * Zlo) + magic, A, C, mode, res, sc) >= k) X = -kInf;
             else {
                 long long a = Zlo, b = Zhi;                                    // F(a) < k <= F(b)
                 while (b - a > 1) {
                     const long long mid = a + ((b - a) >> 1);
-                    if (qnn_fold_code((int)(dir * mid), A, res, sc) >= k) b = mid; else a = mid;
+                    if (qnn_fold_code((int)(dir * mid) + magic, A, C, mode, res, sc) >= k) b = mid; else a = mid;
                 }
                 X = b;
             }
@@ -162,28 +167,32 @@ __global__ __launch_bounds__(kThreads) void k_fold_prepare(FoldProblem p) {
         else bz = bnz < blo ? blo : bnz > bhi ? bhi : bnz;
         if (bz > (1LL << 30) || bz < -(1LL << 30)) continue;
         const int beta = (int)(dir * bz);
+        // (mode 2: outside |accw + beta| < 2^22 the accumulator's bits leave the binade of the magic constant; positive floats
+        // order like their bit patterns, so the folded form stays monotone there and merely saturates -- whether the
+        // thresholds all lie inside is decided by the sweep below, like everything else)
         // ---- 4. proof: every point of the domain ----
         long long bad = 0;
         for (long long i = t; i < npts; i += kThreads) {
             const int s = sc0 + (int)(i % nsc);
             const int acc = (int)(dir * (zlo + i / nsc));
-            bad += chain_code(p, c, acc, s) != qnn_fold_code(256 * acc + beta, A, res, s);
+            bad += chain_code(p, c, acc, s) != qnn_fold_code(256 * acc + beta + magic, A, C, mode, res, s);
         }
         bad = block_sum(bad, sh);
         if (bad == 0) {
-            if (t == 0) { p.A[c] = A; p.beta[c] = beta; p.status[c] = 1; p.points[c] = (unsigned long long)npts; }
+            if (t == 0) { p.A[c] = A; p.beta[c] = beta + magic; p.C[c] = C; p.status[c] = 1; p.points[c] = (unsigned long long)npts; }
             return;
         }
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_fold_eval(const float* __restrict__ A, const int32_t* __restrict__ beta, int c,
+__global__ __launch_bounds__(kThreads) void k_fold_eval(const float* __restrict__ A, const int32_t* __restrict__ beta,
+                                                        const float* __restrict__ C, int mode, int c,
                                                         int has_res, const int32_t* __restrict__ acc,
                                                         const int32_t* __restrict__ sc, int32_t* __restrict__ codes, size_t n) {
-    const float a = A[c];
+    const float a = A[c], cc = C[c];
     const int b = beta[c];
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
-        codes[i] = qnn_fold_code(256 * acc[i] + b, a, has_res != 0, has_res ? sc[i] : 0);
+        codes[i] = qnn_fold_code(256 * acc[i] + b, a, cc, mode, has_res != 0, has_res ? sc[i] : 0);
 }
 
 }  // namespace
@@ -221,6 +230,7 @@ extern "C" int qnn_fold_prepare(const qnn_weights_t* w, int x_store, int x_bits,
     auto fail = [&](int code) {
         if (f->d_a) (void)hipFree(f->d_a);
         if (f->d_b) (void)hipFree(f->d_b);
+        if (f->d_c) (void)hipFree(f->d_c);
         if (d_status) (void)hipFree(d_status);
         if (d_dom) (void)hipFree(d_dom);
         if (d_points) (void)hipFree(d_points);
@@ -237,6 +247,7 @@ extern "C" int qnn_fold_prepare(const qnn_weights_t* w, int x_store, int x_bits,
     } while (0)
     FOLD_HIP(hipMalloc(&f->d_a, sizeof(float) * w->cout));
     FOLD_HIP(hipMalloc(&f->d_b, sizeof(int32_t) * w->cout));
+    FOLD_HIP(hipMalloc(&f->d_c, sizeof(float) * w->cout));
     FOLD_HIP(hipMalloc(&d_status, sizeof(int32_t) * w->cout));
     FOLD_HIP(hipMalloc(&d_dom, sizeof(int32_t) * 2 * w->cout));
     FOLD_HIP(hipMalloc(&d_points, sizeof(unsigned long long) * w->cout));
@@ -254,29 +265,36 @@ extern "C" int qnn_fold_prepare(const qnn_weights_t* w, int x_store, int x_bits,
     p.has_res = f->has_res;
     p.res_scale = ldexpf(1.0f, -(4 - 1));
     p.post_scale = f->post_scale;
-    p.A = f->d_a; p.beta = f->d_b; p.status = d_status; p.dom = d_dom; p.points = d_points;
-    hipLaunchKernelGGL(k_fold_prepare, dim3((unsigned)w->cout), dim3(kThreads), 0, s, p);
-    FOLD_HIP(hipGetLastError());
+    p.A = f->d_a; p.beta = f->d_b; p.C = f->d_c; p.status = d_status; p.dom = d_dom; p.points = d_points;
     int32_t* h_status = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)w->cout);
     unsigned long long* h_points = (unsigned long long*)malloc(sizeof(unsigned long long) * (size_t)w->cout);
     if (!h_status || !h_points) { free(h_status); free(h_points); qnn_set_error("qnn_fold_prepare: out of host memory"); return fail(QNN_ENOMEM); }
-    hipError_t he = hipMemcpyAsync(h_status, d_status, sizeof(int32_t) * w->cout, hipMemcpyDeviceToHost, s);
-    if (he == hipSuccess) he = hipMemcpyAsync(h_status + w->cout, d_dom, sizeof(int32_t) * 2 * w->cout, hipMemcpyDeviceToHost, s);
-    if (he == hipSuccess) he = hipMemcpyAsync(h_points, d_points, sizeof(unsigned long long) * w->cout, hipMemcpyDeviceToHost, s);
-    if (he == hipSuccess) he = hipStreamSynchronize(s);
-    if (he != hipSuccess) {
-        free(h_status); free(h_points);
-        qnn_set_error("qnn_fold_prepare: %s", hipGetErrorString(he));
-        return fail(QNN_EHIP);
-    }
-    f->folded = 0; f->points = 0;
-    f->acc_lo = 0; f->acc_hi = 0;
-    for (int c = 0; c < w->cout; ++c) {
-        f->folded += h_status[c] != 0;
-        f->points += (long long)h_points[c];
-        const int lo = h_status[w->cout + 2 * c], hi = h_status[w->cout + 2 * c + 1];
-        if (c == 0 || lo < f->acc_lo) f->acc_lo = lo;
-        if (c == 0 || hi > f->acc_hi) f->acc_hi = hi;
+    // the "bits" form first (one instruction fewer per value; needs the accumulators inside +-2^22 on every channel),
+    // the conversion form if some channel has no fold in it
+    for (int mode = 2; mode >= 1; --mode) {
+        p.mode = mode;
+        hipLaunchKernelGGL(k_fold_prepare, dim3((unsigned)w->cout), dim3(kThreads), 0, s, p);
+        hipError_t he = hipGetLastError();
+        if (he == hipSuccess) he = hipMemcpyAsync(h_status, d_status, sizeof(int32_t) * w->cout, hipMemcpyDeviceToHost, s);
+        if (he == hipSuccess) he = hipMemcpyAsync(h_status + w->cout, d_dom, sizeof(int32_t) * 2 * w->cout, hipMemcpyDeviceToHost, s);
+        if (he == hipSuccess) he = hipMemcpyAsync(h_points, d_points, sizeof(unsigned long long) * w->cout, hipMemcpyDeviceToHost, s);
+        if (he == hipSuccess) he = hipStreamSynchronize(s);
+        if (he != hipSuccess) {
+            free(h_status); free(h_points);
+            qnn_set_error("qnn_fold_prepare: %s", hipGetErrorString(he));
+            return fail(QNN_EHIP);
+        }
+        f->mode = mode;
+        f->folded = 0; f->points = 0;
+        f->acc_lo = 0; f->acc_hi = 0;
+        for (int c = 0; c < w->cout; ++c) {
+            f->folded += h_status[c] != 0;
+            f->points += (long long)h_points[c];
+            const int lo = h_status[w->cout + 2 * c], hi = h_status[w->cout + 2 * c + 1];
+            if (c == 0 || lo < f->acc_lo) f->acc_lo = lo;
+            if (c == 0 || hi > f->acc_hi) f->acc_hi = hi;
+        }
+        if (f->folded == w->cout) break;
     }
     free(h_status); free(h_points);
     (void)hipFree(d_status); (void)hipFree(d_dom); (void)hipFree(d_points);
@@ -289,6 +307,7 @@ extern "C" int qnn_fold_free(qnn_fold_t* f) {
     if (!f) return QNN_OK;
     if (f->d_a) (void)hipFree(f->d_a);
     if (f->d_b) (void)hipFree(f->d_b);
+    if (f->d_c) (void)hipFree(f->d_c);
     free(f);
     return QNN_OK;
 }
@@ -302,11 +321,13 @@ extern "C" int qnn_fold_info(const qnn_fold_t* f, qnn_fold_info_t* info) {
     info->points = f->points;
     info->acc_lo = f->acc_lo;
     info->acc_hi = f->acc_hi;
+    info->mode = f->mode;
     return QNN_OK;
 }
 
-extern "C" int qnn_fold_constants(const qnn_fold_t* f, float* A, int32_t* beta, void* stream) {
+extern "C" int qnn_fold_constants(const qnn_fold_t* f, float* A, int32_t* beta, float* C, void* stream) {
     QNN_REQUIRE(f && A && beta, QNN_EINVAL, "qnn_fold_constants: null pointer");
+    if (C) QNN_HIP(hipMemcpyAsync(C, f->d_c, sizeof(float) * f->cout, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     QNN_HIP(hipMemcpyAsync(A, f->d_a, sizeof(float) * f->cout, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     QNN_HIP(hipMemcpyAsync(beta, f->d_b, sizeof(int32_t) * f->cout, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return QNN_OK;
@@ -320,8 +341,8 @@ extern "C" int qnn_fold_eval(const qnn_fold_t* f, int c, const int32_t* acc, con
     if (n == 0) return QNN_OK;
     size_t blocks = (n + kThreads - 1) / kThreads;
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(k_fold_eval, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, f->d_a, f->d_b, c,
-                       f->has_res, acc, sc, codes, n);
+    hipLaunchKernelGGL(k_fold_eval, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, f->d_a, f->d_b, f->d_c,
+                       f->mode, c, f->has_res, acc, sc, codes, n);
     QNN_HIP(hipGetLastError());
     return QNN_OK;
 }

@@ -77,7 +77,7 @@ __device__ __forceinline__ void strip_block_map(int& xw, int& yblk) {
 // cvt + mul, per pair one v_cvt_pknorm_i16_f32 (+ two v_pk_add_i16 clamp with a shortcut), and the nibbles of a lane's
 // field are gathered with two v_perm_b32 + shift + v_bfi_b32 (NT = 2) instead of cvt, [add], mul, add, [bfe, cvt, fma],
 // add, v_med3 and a shift-or per value.
-template <int CIN, int NT, int RES, bool BIAS, bool FOLD>   // RES: 0 none, 1 packed int4 shortcut, 2 float32 shortcut
+template <int CIN, int NT, int RES, bool BIAS, int FOLD>   // RES: 0 none, 1 packed int4 shortcut, 2 float32 shortcut; FOLD: 0 chain, 1 / 2 = fold modes (qnn_fold.h)
 __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RES == 2 ? 2 : QNN_STRIP32_WPS) : QNN_STRIP64_WPS)) void k_conv_strip(MfmaGeom mg, EpiArgs e,
                                                                  const uint8_t* __restrict__ x,
                                                                  const uint8_t* __restrict__ wq8,
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
     const v2f rcoef2 = {rcoef, rcoef};
     // folded epilogue: per-channel slope and accumulator offset (the MFMA chain starts from the offset)
     static_assert(!FOLD || RES != 2, "the float32 shortcut is not folded");
-    float fa[NT][4];
+    float fa[NT][4], fc[NT][4];
     v4i binit[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
         for (int i = 0; i < 4; ++i) {
             const int c = nbase + 4 * NT * kq + 4 * nt + i;
             fa[nt][i] = FOLD ? e.fold_a[c] : 0.0f;
+            fc[nt][i] = FOLD == 2 ? e.fold_c[c] : 0.0f;
             binit[nt][i] = FOLD ? e.fold_b[c] : 0;
         }
     // round-half-even + clamp + offset code in the integer domain: as_int(u + (1.5*2^23 + 8)) = 0x4B400008 + rint(u)
@@ -283,8 +284,8 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
                 // ---- folded epilogue (qnn_fold.h) ----
                 if constexpr (NT == 1) {
                     // pairs (c0, c2), (c1, c3): codes in bits 12-15 / 28-31 of a pair
-                    uint32_t pe = qnn_fold_pair(acc[0][0], acc[0][2], fa[0][0], fa[0][2]);
-                    uint32_t po = qnn_fold_pair(acc[0][1], acc[0][3], fa[0][1], fa[0][3]);
+                    uint32_t pe = qnn_fold_pair_m<FOLD>(acc[0][0], acc[0][2], fa[0][0], fa[0][2], fc[0][0], fc[0][2]);
+                    uint32_t po = qnn_fold_pair_m<FOLD>(acc[0][1], acc[0][3], fa[0][1], fa[0][3], fc[0][1], fc[0][3]);
                     if constexpr (RES == 1) {
                         // shortcut field (16 bits): nibbles -> offset codes (sc + 8) << 10 in the halves of a pair
                         const uint32_t w = rcur[0] ^ 0x8888u;
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
                     static_assert(NT <= 2, "a lane's fields must fit one word");
                     uint32_t tp[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) tp[j] = qnn_fold_pair(acc[0][j], acc[1][j], fa[0][j], fa[1][j]);   // (c_j, c_j+4)
+                    for (int j = 0; j < 4; ++j)
+                        tp[j] = qnn_fold_pair_m<FOLD>(acc[0][j], acc[1][j], fa[0][j], fa[1][j], fc[0][j], fc[1][j]);   // (c_j, c_j+4)
                     if constexpr (RES == 1) {
                         const uint32_t w = rcur[0] ^ 0x88888888u;
                         tp[0] = qnn_fold_merge(tp[0], (w & 0x000F000Fu) << 10);
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
 // output row, so every output row simply requests its three input rows (one output row ahead) and widens them.
 // B operand of lane (pixel r, k-block): input pixel 2*(xs + r) - pl + dx.
 // ---------------------------------------------------------------------------------------------------------
-template <int CIN, int NT, bool BIAS, bool FOLD>
+template <int CIN, int NT, bool BIAS, int FOLD>
 __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(MfmaGeom mg, EpiArgs e,
                                                                              const uint8_t* __restrict__ x,
                                                                              const uint8_t* __restrict__ wq8,
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
             ninv[nt][i >> 1][i & 1] = __fmul_rn(__fmul_rn(e.bn_inv ? e.bn_inv[c] : 1.0f, e.scale), cfold);
             nshift[nt][i >> 1][i & 1] = __fmul_rn(e.bn_inv ? e.bn_shift[c] : 0.0f, cfold);
         }
-    float fa[NT][4];                                   // folded epilogue (k_conv_strip): slope and accumulator offset
+    float fa[NT][4], fc[NT][4];                        // folded epilogue (k_conv_strip): slope, constant and accumulator offset
     v4i binit[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
         for (int i = 0; i < 4; ++i) {
             const int c = nbase + 4 * NT * kq + 4 * nt + i;
             fa[nt][i] = FOLD ? e.fold_a[c] : 0.0f;
+            fc[nt][i] = FOLD == 2 ? e.fold_c[c] : 0.0f;
             binit[nt][i] = FOLD ? e.fold_b[c] : 0;
         }
     constexpr float kMagic = 12582920.0f;
@@ -528,7 +531,8 @@ __global__ __launch_bounds__(256, (CIN == 16 ? 4 : 2)) void k_conv_strip_s2(Mfma
             if constexpr (FOLD) {
                 uint32_t tp[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) tp[j] = qnn_fold_pair(acc[0][j], acc[1][j], fa[0][j], fa[1][j]);   // (c_j, c_j+4)
+                for (int j = 0; j < 4; ++j)
+                    tp[j] = qnn_fold_pair_m<FOLD>(acc[0][j], acc[1][j], fa[0][j], fa[1][j], fc[0][j], fc[1][j]);   // (c_j, c_j+4)
                 const uint32_t uo = __builtin_amdgcn_perm(tp[3], tp[1], 0x07030501u);
                 const uint32_t ue = __builtin_amdgcn_perm(tp[2], tp[0], 0x07030501u);
                 __builtin_amdgcn_raw_buffer_store_b32((uo & 0xF0F0F0F0u) | ((ue >> 4) & 0x0F0F0F0Fu), yr, ovoff, 0, 0);
@@ -602,16 +606,20 @@ int launch_strip_s2(const MfmaGeom& mg, const EpiArgs& e, const void* x, const u
     long blocks = (ntasks_l + 3) / 4;
     if (blocks > blocks_cap) blocks = blocks_cap;
     const dim3 grid((unsigned)blocks, (unsigned)ny), block(256);
-    if (e.fold_a)            // folded epilogue (the bias is inside the fold)
-        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false, true>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+    if (e.fold_a && e.fold_c)   // folded epilogue (the bias is inside the fold), "bits" form
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false, 2>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+                           spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
+                           (uint32_t)img_x, (uint32_t)img_y);
+    else if (e.fold_a)
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false, 1>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
                            spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
                            (uint32_t)img_x, (uint32_t)img_y);
     else if (e.bias)
-        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, true, false>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, true, 0>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
                            spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
                            (uint32_t)img_x, (uint32_t)img_y);
     else
-        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false, false>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
+        hipLaunchKernelGGL((k_conv_strip_s2<CIN, NT, false, 0>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l,
                            spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc,
                            (uint32_t)img_x, (uint32_t)img_y);
     return 0;
@@ -655,10 +663,10 @@ int launch_strip(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
         return 0;                                                                                             \
     }
     // folded epilogue: everything behind the accumulator (bias included) is inside the fold's two constants
-    const bool fold = e.fold_a != nullptr && res != 2;
-    STRIP_CASE(0, false, true) STRIP_CASE(1, false, true)
-    STRIP_CASE(0, false, false) STRIP_CASE(0, true, false) STRIP_CASE(1, false, false) STRIP_CASE(1, true, false)
-    STRIP_CASE(2, false, false) STRIP_CASE(2, true, false)
+    const int fold = (e.fold_a == nullptr || res == 2) ? 0 : e.fold_c ? 2 : 1;
+    STRIP_CASE(0, false, 2) STRIP_CASE(1, false, 2) STRIP_CASE(0, false, 1) STRIP_CASE(1, false, 1)
+    STRIP_CASE(0, false, 0) STRIP_CASE(0, true, 0) STRIP_CASE(1, false, 0) STRIP_CASE(1, true, 0)
+    STRIP_CASE(2, false, 0) STRIP_CASE(2, true, 0)
 #undef STRIP_CASE
     return 1;
 }

@@ -7,9 +7,10 @@
 // without the input loads, 12.0 us with neither.  So the memory instructions are made few and wide:
 //
 //   * INPUT: staged through LDS.  One 16-byte load per lane brings SIX rows of the strip (20 pixels = 160 bytes per row
-//     incl. the halo, ten lanes per row) into four registers; six rows later one ds_write_b128 puts them into a
-//     wave-private ring of two 1-KiB slots, and a row's operand is one ds_read_b64 per lane at an immediate offset:
-//     1/6 instead of 1 vector-memory instruction per row.  (LDS-DMA, buffer_load ... lds, would save the registers,
+//     incl. the halo, ten lanes per row) into four registers; six rows later they are widened to code * 16 bytes (once
+//     per pixel instead of once per tap and row) and two ds_write_b128 put them into a wave-private ring of two 2-KiB
+//     slots; a row's MFMA operand is one ds_read_b128 per lane at an immediate offset, no arithmetic: 1/6 instead of 1
+//     vector-memory instruction and 2 instead of 6 widening instructions per row.  (LDS-DMA, buffer_load ... lds, would save the registers,
 //     but the compiler guards every LDS read behind a pending DMA with s_waitcnt vmcnt(0) and hoists reads over hand
 //     placed counts -- measured in the ISA; ordinary loads are counted exactly by the compiler itself.)
 //   * SHORTCUT (residual merge): the same, eight lanes per row, six rows per load; a lane's four codes are one
@@ -32,15 +33,24 @@
 
 namespace {
 
-constexpr int kSlot = 1024;                 // bytes one LDS-DMA instruction writes (64 lanes x 16 bytes)
-constexpr int kXRow = 160, kSRow = 128;     // bytes per staged input row (20 pixels) / shortcut row (16 pixels)
+constexpr int kXSlot = 2048, kSSlot = 1024; // bytes of a six-row group in LDS: 64 lanes x 32 bytes (widened) / x 16 bytes
+constexpr int kXRow = 320, kSRow = 128;     // bytes per staged input row (20 widened pixels) / shortcut row (16 pixels)
 
-template <bool RES>
-__global__ __launch_bounds__(256, 6) void k_conv_strip16_lds(MfmaGeom mg, EpiArgs e, const uint8_t* __restrict__ x,
+// Occupancy (round 4, 64 x 224 x 224: 21.9 us at 6 waves per SIMD, 19.5 / 18.4 / 16.6 / 18.0 / 26.6 us at 5 / 4 / 3 / 2 / 1): the
+// persistent grid runs THREE waves per SIMD -- each wave then owns ~76 rows of a strip instead of ~38 (half the ring
+// fills) and three waves already cover one another's LDS and matrix-pipe latencies; the register bound is left at four.
+#ifndef QNN_S16_BOUNDS
+#define QNN_S16_BOUNDS 4
+#endif
+#ifndef QNN_S16_WPS
+#define QNN_S16_WPS 3
+#endif
+template <bool RES, int FOLD>
+__global__ __launch_bounds__(256, QNN_S16_BOUNDS) void k_conv_strip16_lds(MfmaGeom mg, EpiArgs e, const uint8_t* __restrict__ x,
                                                              const uint8_t* __restrict__ wq8, void* __restrict__ y,
                                                              int ntasks, int spr, FastDiv fd_spr, int nch, FastDiv fd_nch,
                                                              int rc, uint32_t img_x, uint32_t img_y) {
-    constexpr int WB = RES ? 4 * kSlot : 2 * kSlot;              // LDS bytes per wave
+    constexpr int WB = 2 * kXSlot + (RES ? 2 * kSSlot : 0);      // LDS bytes per wave
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * WB];
     const ConvGeom& g = mg.g;
     const int lane = threadIdx.x & 63;
@@ -48,7 +58,7 @@ __global__ __launch_bounds__(256, 6) void k_conv_strip16_lds(MfmaGeom mg, EpiArg
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     uint8_t* const xs_lds = smem + wave * WB;                    // two input slots, then two shortcut slots
-    uint8_t* const ss_lds = xs_lds + 2 * kSlot;
+    uint8_t* const ss_lds = xs_lds + 2 * kXSlot;
 
     // ---- filters: A operand, row = output channel (as k_conv_strip<16, 1>) ----
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wq8), 0, (int)mg.w_bytes, 0x00020000);
@@ -58,13 +68,16 @@ __global__ __launch_bounds__(256, 6) void k_conv_strip16_lds(MfmaGeom mg, EpiArg
         const int woff = kq < 3 ? (r * 9 + dy * 3 + kq) * 16 : (int)0x80000000;
         bw[dy] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff, 0, 0));
     }
-    float fa[4];
+    float fa[4], fc[4];
     v4i binit;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { fa[i] = e.fold_a[4 * kq + i]; binit[i] = e.fold_b[4 * kq + i]; }
+    for (int i = 0; i < 4; ++i) {
+        fa[i] = e.fold_a[4 * kq + i]; binit[i] = e.fold_b[4 * kq + i];
+        fc[i] = FOLD == 2 ? e.fold_c[4 * kq + i] : 0.0f;
+    }
     const int rowb = g.W * 8;                                     // bytes per row: input, output and shortcut alike
     // LDS read addresses of this lane: pixel xs + r + dx - 1 is entry r + dx + 1 of a staged row (it starts at xs - 2)
-    const uint8_t* const xrd = xs_lds + (r + (kq < 3 ? kq : 0) + 1) * 8;
+    const uint8_t* const xrd = xs_lds + (r + (kq < 3 ? kq : 0) + 1) * 16;
     const uint8_t* const srd = ss_lds + r * 8 + kq * 2;
     // DMA lanes: input row = lane / 10 (lanes 60..63 idle), pixel pair lane % 10; shortcut row = lane / 8 (48..63 idle)
     const int xl_row = lane / 10, xl_c = lane - 10 * xl_row;
@@ -104,8 +117,15 @@ __global__ __launch_bounds__(256, 6) void k_conv_strip16_lds(MfmaGeom mg, EpiArg
                 sv += 6 * rowb;
             }
         };
-        auto xput = [&](int slot) { *reinterpret_cast<uint4*>(xs_lds + slot * kSlot + lane * 16) = xg; };
-        auto sput = [&](int slot) { if constexpr (RES) *reinterpret_cast<uint4*>(ss_lds + slot * kSlot + lane * 16) = sg; };
+        // the int4 codes are widened to code * 16 bytes ONCE, on their way into LDS (12 instructions per six rows instead
+        // of 6 per row): a row's operand is then one ds_read_b128 and no arithmetic
+        auto xput_v = [&](int slot, const uint4& v) {
+            v4i* dst = reinterpret_cast<v4i*>(xs_lds + slot * kXSlot + lane * 32);
+            dst[0] = widen(make_uint2(v.x, v.y));
+            dst[1] = widen(make_uint2(v.z, v.w));
+        };
+        auto xput = [&](int slot) { xput_v(slot, xg); };
+        auto sput = [&](int slot) { if constexpr (RES) *reinterpret_cast<uint4*>(ss_lds + slot * kSSlot + lane * 16) = sg; };
         // output: lane (r, kq) stores pixel xs + r of row (first row of the four-row group) + kq
         const bool pvalid = xs + r < g.W;
         int orow = y0 + kq;
@@ -118,16 +138,16 @@ __global__ __launch_bounds__(256, 6) void k_conv_strip16_lds(MfmaGeom mg, EpiArg
             xload(); sload();
             const uint4 x1 = xg, s1 = sg;
             xload(); sload();                                    // (three loads of each ring in flight before the first wait)
-            *reinterpret_cast<uint4*>(xs_lds + lane * 16) = x0;
-            *reinterpret_cast<uint4*>(xs_lds + kSlot + lane * 16) = x1;
+            xput_v(0, x0);
+            xput_v(1, x1);
             if constexpr (RES) {
                 *reinterpret_cast<uint4*>(ss_lds + lane * 16) = s0;
-                *reinterpret_cast<uint4*>(ss_lds + kSlot + lane * 16) = s1;
+                *reinterpret_cast<uint4*>(ss_lds + kSSlot + lane * 16) = s1;
             }
         }
         v4i X[3];
-        X[0] = widen(*reinterpret_cast<const uint2*>(xrd + 0 * kXRow));
-        X[1] = widen(*reinterpret_cast<const uint2*>(xrd + 1 * kXRow));
+        X[0] = *reinterpret_cast<const v4i*>(xrd + 0 * kXRow);
+        X[1] = *reinterpret_cast<const v4i*>(xrd + 1 * kXRow);
         uint32_t R[4] = {0, 0, 0, 0};                            // a four-row group's fields (bytes 1 and 3 of each)
 
         auto store_group = [&](bool all) {
@@ -149,18 +169,17 @@ __global__ __launch_bounds__(256, 6) void k_conv_strip16_lds(MfmaGeom mg, EpiArg
         auto body = [&](auto jc, bool full) {
             constexpr int J = decltype(jc)::value;
             constexpr int I = (J + 2) % 12;                      // ring position of the input row this body brings in
-            const uint2 rw = *reinterpret_cast<const uint2*>(xrd + (I / 6) * kSlot + (I % 6) * kXRow);
-            X[(J + 2) % 3] = widen(rw);
+            X[(J + 2) % 3] = *reinterpret_cast<const v4i*>(xrd + (I / 6) * kXSlot + (I % 6) * kXRow);
             uint32_t scf = 0;
             if constexpr (RES) {
-                scf = *reinterpret_cast<const unsigned short*>(srd + (J / 6) * kSlot + (J % 6) * kSRow);
+                scf = *reinterpret_cast<const unsigned short*>(srd + (J / 6) * kSSlot + (J % 6) * kSRow);
             }
             v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[0], X[J % 3], binit, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[1], X[(J + 1) % 3], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[2], X[(J + 2) % 3], acc, 0, 0, 0);
             // folded epilogue (qnn_fold.h), pairs (c0, c2), (c1, c3)
-            uint32_t pe = qnn_fold_pair(acc[0], acc[2], fa[0], fa[2]);
-            uint32_t po = qnn_fold_pair(acc[1], acc[3], fa[1], fa[3]);
+            uint32_t pe = qnn_fold_pair_m<FOLD>(acc[0], acc[2], fa[0], fa[2], fc[0], fc[2]);
+            uint32_t po = qnn_fold_pair_m<FOLD>(acc[1], acc[3], fa[1], fa[3], fc[1], fc[3]);
             if constexpr (RES) {
                 const uint32_t w = scf ^ 0x8888u;
                 const uint32_t y2 = __builtin_amdgcn_perm(0u, w, 0x0C010C00u);
@@ -207,7 +226,7 @@ int qnn_launch_strip16_lds(const MfmaGeom& mg, const EpiArgs& e, const void* x, 
     const int spr = (g.W + 15) / 16;
     const double img = (double)g.H * g.W * 8.0;
     if (img >= 1.0e9) return 1;
-    constexpr int wps = 6;
+    static const int wps = QNN_ENV_INT("QNN_S16_WPS", QNN_S16_WPS);       // (A/B switch, experiment builds only)
     const int blocks_cap = 256 * wps;
     const long nwaves = (long)blocks_cap * 4;
     // rows per task: whole rounds of the persistent grid; a round costs rc rows + ~3 rows of pipeline fill.  Multiples of
@@ -226,11 +245,13 @@ int qnn_launch_strip16_lds(const MfmaGeom& mg, const EpiArgs& e, const void* x, 
     long blocks = (ntasks_l + 3) / 4;
     if (blocks > blocks_cap) blocks = blocks_cap;
     const dim3 grid((unsigned)blocks), block(256);
-    if (res)
-        hipLaunchKernelGGL((k_conv_strip16_lds<true>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l, spr,
-                           qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc, (uint32_t)img, (uint32_t)img);
-    else
-        hipLaunchKernelGGL((k_conv_strip16_lds<false>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l, spr,
-                           qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc, (uint32_t)img, (uint32_t)img);
+#define S16_CASE(RES_, FOLD_)                                                                                            \
+    if ((res != 0) == RES_ && fold == FOLD_)                                                                             \
+        hipLaunchKernelGGL((k_conv_strip16_lds<RES_, FOLD_>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, (int)ntasks_l, \
+                           spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc, (uint32_t)img,  \
+                           (uint32_t)img);
+    const int fold = e.fold_c ? 2 : 1;
+    S16_CASE(false, 1) S16_CASE(false, 2) S16_CASE(true, 1) S16_CASE(true, 2)
+#undef S16_CASE
     return 0;
 }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libqnn_hip.so does not export %s" % n
     assert sorted(names) == sorted(_abi.EXPORTS)
-    assert _abi.load().qnn_version() == 3
+    assert _abi.load().qnn_version() == 4
 
 
 def test_no_cpu_fallback():

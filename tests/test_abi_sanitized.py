@@ -56,7 +56,7 @@ CHILD = textwrap.dedent(r'''
             assert msg, what + ": no message in qnn_last_error()"
         return msg
 
-    assert lib.qnn_version() == 3
+    assert lib.qnn_version() == 4
     expect(lib.qnn_set_conv_impl(5), EINVAL, "set_conv_impl(5)")
     expect(lib.qnn_set_conv_impl(-1), EINVAL, "set_conv_impl(-1)")
     expect(lib.qnn_set_conv_impl(0), 0, "set_conv_impl(0)")
@@ -117,6 +117,21 @@ CHILD = textwrap.dedent(r'''
     expect(lib.qnn_dense_forward(None, FAKE, 4, 4, 1, None, FAKE, None), EINVAL, "dense null handle")
     expect(lib.qnn_conv2d_forward_f32in(None, FAKE, 1, 1, 1, 8, 8, None, FAKE, None, 0, None), EINVAL, "f32in null handle")
     assert lib.qnn_conv2d_workspace_bytes(None, 1, 8, 8) == 0
+    # the fold entry points (ABI 4): null handles / pointers
+    lib.qnn_fold_prepare.argtypes = [vp, ci, ci, vp, vp, ctypes.POINTER(vp)]
+    lib.qnn_fold_free.argtypes = [vp]
+    lib.qnn_fold_info.argtypes = [vp, vp]
+    lib.qnn_fold_constants.argtypes = [vp, vp, vp, vp, vp]
+    lib.qnn_fold_eval.argtypes = [vp, ci, vp, vp, vp, sz, vp]
+    fo = vp(0)
+    expect(lib.qnn_fold_prepare(None, 4, 4, FAKE, None, ctypes.byref(fo)), EINVAL, "fold_prepare null weights")
+    expect(lib.qnn_fold_prepare(FAKE, 4, 4, None, None, ctypes.byref(fo)), EINVAL, "fold_prepare null epilogue")
+    expect(lib.qnn_fold_prepare(FAKE, 4, 4, FAKE, None, None), EINVAL, "fold_prepare null out")
+    assert not fo.value
+    expect(lib.qnn_fold_free(None), 0, "fold_free(NULL)")
+    expect(lib.qnn_fold_info(None, FAKE), EINVAL, "fold_info null handle")
+    expect(lib.qnn_fold_constants(None, FAKE, FAKE, None, None), EINVAL, "fold_constants null handle")
+    expect(lib.qnn_fold_eval(None, 0, FAKE, None, FAKE, 4, None), EINVAL, "fold_eval null handle")
     assert lib.qnn_last_kernel() is not None
     print("sanitized ABI checks passed:", n[0])
 ''')
