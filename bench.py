@@ -67,10 +67,16 @@ def parse_args(argv=None):
                          "(0 = per workload: 3 for vgg_large_full_qnn_w8a8, measured +2.5 %, else 2)")
     ap.add_argument("--impl", default="auto", choices=["auto", "valu", "mfma"],
                     help="conv kernel family (results are bit-identical)")
-    ap.add_argument("--first-layer", default="image", choices=["exact", "image", "fixed", "u8"],
-                    help="how the images enter: float32 = bytes / 255 with the kernel named (image: recognised as bytes, "
-                         "default; exact: float32 FMA chain; fixed: fixed point for [0, 1]) or u8 = the bytes themselves "
-                         "through the typed QNN_STORE_U8 entry.  The other entries are reported beside the headline")
+    ap.add_argument("--first-layer", default="auto", choices=["auto", "exact", "image", "fixed", "u8"],
+                    help="how the images enter: float32 = bytes / 255 with the kernel named (auto: the PRODUCT DEFAULT -- "
+                         "byte kernel with a per-batch domain flag, a batch that is not bytes / 255 is recomputed on the "
+                         "exact kernel; image: byte kernel, QnnError on other inputs; exact: float32 FMA chain; fixed: fixed "
+                         "point for [0, 1]) or u8 = the bytes themselves through the typed QNN_STORE_U8 entry.  The other "
+                         "entries are reported beside the headline")
+    ap.add_argument("--rotate", type=int, default=8,
+                    help="distinct input batches per lane the timed region rotates through (8 x 50 MB > the 256 MB "
+                         "Infinity Cache: the images stream from HBM; 1 = replay one cache-resident batch, reported "
+                         "beside the headline as `cache_resident`)")
     ap.add_argument("--no-targets", action="store_true", help="skip the north-star target block (layer ops, other workloads)")
     ap.add_argument("--no-alternatives", action="store_true",
                     help="skip the other first-layer entries and the Model.predict figure (profiling runs)")
@@ -317,7 +323,7 @@ def measure_targets(torch, pkg, args, budget_s=40.0):
         # every workload takes the images the way the headline does (VGG-large's 3 -> 256 first layer and the ResNet
         # stem run on the un-pooled form of the byte kernel)
         model = engine.FusedModel(spec, first_layer=args.first_layer if args.first_layer != "u8" else "exact") \
-            if fused else engine.ResidualFusedModel(spec, first_layer="image" if args.first_layer == "image" else "exact")
+            if fused else engine.ResidualFusedModel(spec, first_layer=args.first_layer if args.first_layer in ("auto", "image") else "exact")
         n = BATCH if fused else 64
         xi = nets.synthetic_images_u8(cf, n, nets.SEED_BASE + idx) if args.first_layer == "u8" \
             else nets.synthetic_images(cf, n, nets.SEED_BASE + idx)
@@ -347,6 +353,59 @@ def measure_targets(torch, pkg, args, budget_s=40.0):
     out["images_per_s"] = rates
     out["seconds"] = round(time.time() - t_start, 1)
     return out
+
+
+class RingSchedule:
+    """Bookkeeping of ONE lane's two logits rings (N > 1): slot j of 2 G consecutive steps, ring k = j // G.  A ring is
+    handed to one collective when its last slot has been written, and is rewritten only after that collective has been
+    waited for.  Pure index arithmetic over two callables, so that tests can drive it without a process group:
+        gather(k)  -> starts the collective on ring k, returns a handle
+        wait(h)    -> blocks until the collective behind the handle is done
+    `fresh[k]` = slots of ring k written since its last gather (what drain() sends of a partly filled ring is the whole
+    ring, of which only these are new); `log` records ('wait' | 'gather' | 'drain', k, fresh) for the tests."""
+
+    def __init__(self, G, gather, wait):
+        self.G, self.gather, self.wait = int(G), gather, wait
+        self.count = 0
+        self.works = [None, None]
+        self.fresh = [0, 0]
+        self.log = []
+
+    def begin_step(self):
+        """-> (slot j in 0 .. 2G-1) the next step writes; waits for the ring's gather if the step starts rewriting it."""
+        j = self.count % (2 * self.G)
+        k = j // self.G
+        self.count += 1
+        if j % self.G == 0:
+            if self.works[k] is not None:
+                self.wait(self.works[k])
+                self.works[k] = None
+                self.log.append(("wait", k, self.fresh[k]))
+            self.fresh[k] = 0
+        return j
+
+    def end_step(self, j):
+        """the step wrote slot j; a full ring goes into its collective"""
+        k = j // self.G
+        self.fresh[k] = j % self.G + 1
+        if j % self.G == self.G - 1:
+            self.works[k] = self.gather(k)
+            self.log.append(("gather", k, self.fresh[k]))
+
+    def drain(self):
+        """gather the partly filled ring (if any) and wait for everything outstanding; the next step starts a ring"""
+        j = self.count % (2 * self.G)
+        if j % self.G != 0:
+            k = j // self.G
+            if self.works[k] is not None:          # (cannot happen: begin_step waited when it entered the ring)
+                self.wait(self.works[k])
+            self.works[k] = self.gather(k)
+            self.log.append(("drain", k, self.fresh[k]))
+            self.count += self.G - (j % self.G)    # the ring counts as used up
+        for k in range(2):
+            if self.works[k] is not None:
+                self.wait(self.works[k])
+                self.works[k] = None
 
 
 def main_rank(args):
@@ -398,7 +457,7 @@ def main_rank(args):
 
     def make_model(first):
         if not fused:
-            return engine.ResidualFusedModel(spec, first_layer="image" if first == "image" else "exact")
+            return engine.ResidualFusedModel(spec, first_layer=first if first in ("auto", "image") else "exact")
         return engine.FusedModel(spec, first_layer="exact" if first == "u8" else first)
 
     def make_input(first, n, seed):
@@ -486,20 +545,31 @@ def main_rank(args):
     # per slot), so a step is one graph launch and nothing else.  Two rings per lane alternate: a ring is only rewritten
     # after its gather has been waited for.
     G = max(1, args.gather_every)
+    R = max(1, args.rotate)
     pipelined = use_dist and backend != "gloo" and bool(args.graph)
     lanes = []
+    pipe = None
     if args.graph:
         try:
             pipe = engine.Pipelined(model, lanes=max(1, args.inflight), batch_size=N)
             if pipelined:
-                lanes = [dict(ln) for ln in pipe.lanes_for(x, slots=2 * G)]
+                lanes = [dict(ln) for ln in pipe.lanes_for(x, slots=2 * G, inputs=R)]
             else:
-                lanes = [dict(ln) for ln in pipe.lanes_for(x)]
+                lanes = [dict(ln) for ln in pipe.lanes_for(x, inputs=R)]
         except Exception as exc:  # pragma: no cover
             print("hipGraph capture failed (%s); running eagerly" % exc, file=sys.stderr)
             lanes = []
     graph = lanes[0]["graph"] if lanes else None
     pipelined = pipelined and graph is not None
+    # every static input buffer of every lane gets its own synthetic batch: R x 50 MB per lane is more than the 256 MB
+    # Infinity Cache, so the timed region reads its images from HBM
+    for li, ln in enumerate(lanes):
+        for ri, xi in enumerate(ln.get("xs", [])):
+            if li == 0 and ri == 0:
+                continue
+            xi.copy_(torch.as_tensor(make_input(args.first_layer, N, nets.SEED_BASE + idx + 1000 * rank + 17 * (li * R + ri))))
+        ln["nin"] = len(ln.get("xs", [])) or 1
+        ln["rot"] = 0
     torch.cuda.synchronize()
     for ln in lanes:
         if pipelined:
@@ -508,9 +578,17 @@ def main_rank(args):
             ln["rings"] = [ln["ring"][:G * B], ln["ring"][G * B:]]
             ln["gathered"] = [torch.empty((world * G * B,) + tuple(ln["y"].shape[1:]), dtype=ln["y"].dtype,
                                           device=ln["y"].device) for _ in range(2)]
-            ln["works"] = [None, None]
-            ln["count"] = 0
+            ln["sched"] = RingSchedule(
+                G, lambda k, ln=ln: dist.all_gather_into_tensor(ln["gathered"][k], ln["rings"][k], async_op=True),
+                lambda h: h.wait())
+            # the `--gather-every 1` figure beside the headline: one collective per batch, two small buffers alternate
+            ln["g1"] = [torch.empty((world * B,) + tuple(ln["y"].shape[1:]), dtype=ln["y"].dtype, device=ln["y"].device)
+                        for _ in range(2)]
+            ln["w1"] = [None, None]
+            ln["c1"] = 0
     counter = [0]
+    rotate_on = [True]
+    every1 = [False]
 
     def run_step():
         if graph is None:
@@ -520,42 +598,54 @@ def main_rank(args):
         counter[0] += 1
         with torch.cuda.stream(ln["stream"]):
             if not pipelined:
-                ln["graph"].replay()
+                r = ln["rot"] % ln["nin"] if rotate_on[0] else 0
+                ln["rot"] += 1
+                (ln["graphs"][r] if "graphs" in ln else ln["graph"]).replay()
                 if use_dist:
-                    shard.gather_logits(ln["y"].cpu() if backend == "gloo" else ln["y"])
+                    yr = ln["ys"][r] if "ys" in ln else ln["y"]
+                    shard.gather_logits(yr.cpu() if backend == "gloo" else yr)
                 return
-            j = ln["count"] % (2 * G)              # slot inside the lane's two rings
-            k = j // G                             # which ring
-            ln["count"] += 1
-            if j % G == 0 and ln["works"][k] is not None:
-                ln["works"][k].wait()              # the ring is about to be rewritten: its gather must have read it
-                ln["works"][k] = None
+            sch = ln["sched"]
+            if every1[0]:
+                # one all-gather per batch (what north_star describes literally); the ring slots are only a place to write
+                j = sch.count % (2 * G)
+                sch.count += 1
+                if ln["direct"]:
+                    ln["graphs"][j].replay()
+                else:
+                    ln["graph"].replay()
+                    ln["ring"][j * ln["B"]:(j + 1) * ln["B"]].copy_(ln["y"], non_blocking=True)
+                k1 = ln["c1"] % 2
+                ln["c1"] += 1
+                if ln["w1"][k1] is not None:
+                    ln["w1"][k1].wait()
+                ln["w1"][k1] = dist.all_gather_into_tensor(ln["g1"][k1], ln["ring"][j * ln["B"]:(j + 1) * ln["B"]], async_op=True)
+                return
+            j = sch.begin_step()                   # slot inside the lane's two rings (waits before a ring is rewritten)
             if ln["direct"]:
                 ln["graphs"][j].replay()           # the last kernel writes straight into slot j
             else:
                 ln["graph"].replay()
                 ln["ring"][j * ln["B"]:(j + 1) * ln["B"]].copy_(ln["y"], non_blocking=True)
-            if j % G == G - 1:
-                ln["works"][k] = dist.all_gather_into_tensor(ln["gathered"][k], ln["rings"][k], async_op=True)
+            sch.end_step(j)
 
     def drain():
-        """Gather what the timed steps left in a partly filled ring (every rank is at the same count: whole rings are
-        gathered, slots not yet rewritten included) and wait for every gather."""
+        """Gather what the timed steps left in a partly filled ring and wait for every gather.  Every rank is at the same
+        count; the whole ring goes into the collective (one fixed-size all-gather), of which only the slots the steps of
+        this region wrote are new -- the rest still hold what an earlier, already gathered round wrote there (zeros before
+        the first).  `ln["fresh"]` records how many slots of each ring are current, for the check behind the region."""
         for ln in lanes:
             if not pipelined:
                 continue
             with torch.cuda.stream(ln["stream"]):
-                j = ln["count"] % (2 * G)
-                if j % G != 0:
-                    k = j // G
-                    if ln["works"][k] is not None:
-                        ln["works"][k].wait()
-                    ln["works"][k] = dist.all_gather_into_tensor(ln["gathered"][k], ln["rings"][k], async_op=True)
-                    ln["count"] += G - (j % G)     # the ring counts as used up
-                for k in range(2):
-                    if ln["works"][k] is not None:
-                        ln["works"][k].wait()
-                        ln["works"][k] = None
+                if every1[0]:
+                    for k1 in range(2):
+                        if ln["w1"][k1] is not None:
+                            ln["w1"][k1].wait()
+                            ln["w1"][k1] = None
+                    ln["sched"].count += (-ln["sched"].count) % G      # the next ring-mode step starts a ring
+                else:
+                    ln["sched"].drain()
 
     def timed_region():
         """EXACTLY --steps steps between two (barrier + synchronize) brackets; MAX over ranks."""
@@ -591,17 +681,59 @@ def main_rank(args):
         if not more:
             break
     dt = float(np.median(regions))
-    model.check_domain()          # "image" / "fixed": every input of the run was inside the kernel's domain (raises otherwise)
+    # "image" / "fixed" / "auto": every input of the run was inside the byte kernel's domain (raises otherwise: a replay
+    # loop, unlike Pipelined.forward, recomputes nothing)
+    (pipe if pipe is not None else model).check_domain()
 
+    # the cache-resident figure beside the headline: the same replay loop on ONE input batch per lane
+    cache_resident = None
+    if lanes and R > 1 and not pipelined:
+        rotate_on[0] = False
+        for _ in range(args.warmup):
+            run_step()
+        rr = [timed_region() for _ in range(max(3, args.repeats))]
+        rotate_on[0] = True
+        cache_resident = {"value": global_batch * args.steps / float(np.median(rr)), "unit": "images/s",
+                          "note": "every lane replays ONE 50 MB input batch, which stays in the 256 MB Infinity Cache"}
+
+    gather_every_1 = None
+    if pipelined and G > 1:
+        every1[0] = True
+        for _ in range(args.warmup):
+            run_step()
+        drain()
+        r1 = [timed_region() for _ in range(max(3, args.repeats))]
+        every1[0] = False
+        gather_every_1 = {"value": global_batch * args.steps / float(np.median(r1)), "unit": "images/s",
+                          "note": "one RCCL all-gather of the logits per batch instead of one per %d batches of a lane" % G}
+
+    ring_check = None
     if pipelined and rank == 0:
-        # a gathered block must hold this rank's ring at its own offset
+        # a gathered block must hold this rank's ring at its own offset, bit for bit and finite; and a ring slot the
+        # region wrote must be what the eager forward gives for that slot's input batch
         torch.cuda.synchronize()
         ln = lanes[0]
         nloc = G * ln["B"]
         for k in range(2):
-            torch.testing.assert_close(ln["gathered"][k][rank * nloc:(rank + 1) * nloc], ln["rings"][k], rtol=0, atol=0,
-                                       equal_nan=True)
+            mine = ln["gathered"][k][rank * nloc:(rank + 1) * nloc]
+            assert bool(torch.isfinite(mine).all()), "non-finite logits in the gathered ring"
+            torch.testing.assert_close(mine, ln["rings"][k], rtol=0, atol=0)
+        j0 = 0
+        eager = model(ln["xs"][j0 % len(ln["xs"])] if "xs" in ln else ln["x"])
+        torch.testing.assert_close(ln["gathered"][0][rank * nloc:rank * nloc + ln["B"]], eager, rtol=0, atol=0)
+        ring_check = "gathered == ring (finite, bit for bit); slot 0 == eager forward of its input batch"
 
+    # which physical devices took part: every rank reports its own (uuid, PCI bus id, name); gathered on rank 0
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    me = {"rank": rank, "uuid": str(getattr(props, "uuid", "")), "name": props.name,
+          "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                            getattr(props, "pci_device_id", 0)),
+          "local_rank": local_rank, "host": socket.gethostname()}
+    devices = [me]
+    if use_dist:
+        got = [None] * world
+        dist.all_gather_object(got, me)
+        devices = got
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = global_batch * args.steps / dt
@@ -646,7 +778,12 @@ def main_rank(args):
                        "hipgraph": graph is not None, "batches_in_flight": len(lanes) if lanes else 1,
                        "parallelism": "dp%d" % world,
                        "dist_backend": backend if use_dist else None,
-                       "rccl_world_size": world if (use_dist and backend == "nccl") else (1 if not use_dist else 0),
+                       "rccl_world_size": (dist.get_world_size() if (use_dist and backend == "nccl") else (1 if not use_dist else 0)),
+                       "devices": devices, "distinct_devices": len(set(d["uuid"] for d in devices)),
+                       "ring_check": ring_check,
+                       "input_batches_per_lane": R if lanes else 1,
+                       "input_bytes_rotated_per_lane": (R if lanes else 1) * int(x.numel()) * x.element_size(),
+                       "cache_resident": cache_resident, "gather_every_1": gather_every_1,
                        "logits_gather": ("one all-gather per %d batches of a lane, asynchronous" % G) if pipelined
                        else ("per batch" if use_dist else None),
                        "timed_regions": len(regions),
@@ -667,8 +804,8 @@ def main_rank(args):
             # of steps per region (NOT the headline; `config.first_layer` names the one `value` was measured with)
             alts = {}
             for first in ("exact", "image", "fixed", "u8"):
-                if first == args.first_layer:
-                    continue
+                if first == args.first_layer or (first == "image" and args.first_layer == "auto"):
+                    continue                                 # ("auto" on dataset images IS the byte kernel of "image")
                 try:
                     m2 = make_model(first)
                     x2 = torch.as_tensor(make_input(first, N, nets.SEED_BASE + idx)).cuda()
@@ -689,9 +826,11 @@ def main_rank(args):
             # images, far more than the 256 MB Infinity Cache): engine.Pipelined's bound launch plans read every batch
             # in place and write the logits in place; the one host synchronisation is predict's domain check at the end
             try:
-                mp = nets.Model(cf, spec, first_layer="exact" if u8 else args.first_layer, lanes=len(lanes))
+                mp = nets.Model(cf, spec, lanes=len(lanes)) if args.first_layer == "auto" else \
+                    nets.Model(cf, spec, first_layer="exact" if u8 else args.first_layer, lanes=len(lanes))
                 nb = 64 if N * cf.dim * cf.dim * cf.channels * 4 * 64 < 8e9 else 8
-                xb = torch.as_tensor(make_input(args.first_layer, N, nets.SEED_BASE + idx)).cuda().repeat(nb, 1, 1, 1)
+                xb = torch.cat([torch.as_tensor(make_input(args.first_layer, N, nets.SEED_BASE + idx + 31 * b)) for b in range(8)]
+                               ).cuda().repeat(nb // 8, 1, 1, 1)
                 mp.predict(xb, batch_size=N)
                 ts = []
                 for _ in range(5):
@@ -702,6 +841,8 @@ def main_rank(args):
                     ts.append(time.perf_counter() - t0)
                 pv = nb * N / float(np.median(ts))
                 out["model_predict_resident"] = {"value": pv, "unit": "images/s", "images": nb * N,
+                                                 "call": "nets.Model(cf, spec).predict(x)  (no arguments: the defaults)"
+                                                 if args.first_layer == "auto" else "nets.Model(cf, spec, first_layer=%r)" % args.first_layer,
                                                  "ratio_to_value": pv / value}
                 del mp, xb, yb
             except Exception as exc:  # pragma: no cover
@@ -728,9 +869,13 @@ def main_rank(args):
 
 FIRST_LAYER_NOTE = {
     "exact": "float32 images, any values: float32 FMA chain on the f32 matrix pipe, bit-exact vs the oracle",
+    "auto": "the product default: float32 images run on the byte kernel of 'image' with one domain-flag word per batch; a "
+            "batch that is not image bytes / 255 is recomputed in-process on the exact kernel (any float tensor is accepted, "
+            "as by the reference's call()); first-layer codes against the reference's own first conv + BN + activation on "
+            "the 4096 benchmark images: see `first_layer_vs_reference` (tests/test_gpu_u8.py asserts the same counts)",
     "image": "float32 images that are bytes / 255 (utils/load_data.py:40): recognised as bytes (|255 x - k| <= 2^-15, else "
              "the layer's domain flag -> QnnError), exact integer sum on the int8 matrix pipe + one FMA; identical to the "
-             "uint8 entry; 0 activation codes differ from the reference's traces (tests/test_gpu_u8.py)",
+             "uint8 entry; see `first_layer_vs_reference` for the measured code differences",
     "fixed": "float32 images in [0, 1] (else domain flag -> QnnError): fixed point at 2^-23, three int8 digit passes",
     "u8": "uint8 image bytes through the typed QNN_STORE_U8 entry of the C ABI: exact integer sum + one FMA",
 }

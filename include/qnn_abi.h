@@ -137,6 +137,11 @@ typedef struct qnn_epilogue {
     float trick_c;           /* output-side identity trick: 1 - 1/klm (ignored when trick_s == 0) */
     float trick_s;           /* klm, or 0 = the trick is the identity (default)                    */
     const qnn_fold_t* fold;  /* qnn_fold_prepare() of exactly this layer + epilogue, or NULL (ABI 4)  */
+    uint32_t* domain_flag;   /* DEVICE-visible word of the CALLER: a restricted-domain first-layer kernel
+                              * (QNN_STORE_F32_IMAGE / _UNIT) that meets an input outside its domain stores a
+                              * non-zero value there instead of raising the layer's own flag -- one word per
+                              * batch in flight lets the caller recompute exactly the affected batch on the
+                              * exact kernel (engine "auto" mode).  NULL = the handle's flag (ABI 4)          */
 } qnn_epilogue_t;
 
 /* ---- library ------------------------------------------------------------ */

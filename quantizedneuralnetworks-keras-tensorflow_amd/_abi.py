@@ -37,7 +37,7 @@ class Epilogue(ctypes.Structure):
                 ("pool", ctypes.c_int32), ("out_store", ctypes.c_int32),
                 ("res", ctypes.c_void_p), ("res_store", ctypes.c_int32), ("res_bits", ctypes.c_int32),
                 ("post_scale", ctypes.c_float), ("trick_c", ctypes.c_float), ("trick_s", ctypes.c_float),
-                ("fold", ctypes.c_void_p)]
+                ("fold", ctypes.c_void_p), ("domain_flag", ctypes.c_void_p)]
 
 
 class FoldInfo(ctypes.Structure):
@@ -293,13 +293,14 @@ def out_hw(size, k, stride, same_pad):
 
 
 def make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res=None, res_store=STORE_F32,
-                  res_bits=0, post_scale=1.0, trick=None, fold=None):
+                  res_bits=0, post_scale=1.0, trick=None, fold=None, domain_flag=None):
     """trick: None (the reference's lr-multiplier identity trick is the identity) or the (c, s) float32 pair of its
     OUTPUT side, `faithful_trick(klm, promotion)`.  fold: a Fold prepared for exactly this layer and epilogue."""
     tc, ts = (float(trick[0]), float(trick[1])) if trick is not None else (0.0, 0.0)
     return Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store,
                     ptr(res).value, res_store, res_bits, float(post_scale), tc, ts,
-                    fold.handle.value if fold is not None else None)
+                    fold.handle.value if fold is not None else None,
+                    ptr(domain_flag).value if domain_flag is not None else None)
 
 
 class Fold:
@@ -371,7 +372,7 @@ def faithful_trick(klm, promotion="nep50"):
 
 def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
            pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0, out=None, trick=None,
-           fold=None):
+           fold=None, domain_flag=None):
     """Run qnn_conv2d_forward; x is a float32 NHWC tensor, a uint8 NHWC tensor or an int32 packed tensor.
     Returns (y, Hp, Wp): y float32 (N,Hp,Wp,cout) or int32 (N*Hp*Wp, words); `out` = a tensor of that shape to write
     into instead of a fresh one."""
@@ -388,7 +389,8 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
         if tuple(out.shape) != shape or out.dtype != dt or not out.is_contiguous() or out.device != x.device:
             raise QnnError("conv2d: `out` must be a contiguous %s tensor of shape %s on %s" % (dt, shape, x.device))
         y = out
-    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale, trick, fold)
+    epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale, trick, fold,
+                        domain_flag)
     check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
                                     ptr(y), stream_ptr()), "qnn_conv2d_forward")
     return y, Ho, Wo
@@ -450,7 +452,9 @@ class BoundStep:
         self._h = w.handle
         self._what = "qnn_%s_forward" % ("conv2d" if kind == "conv" else "dense")
 
-    def __call__(self, stream, x_ptr=None, y_ptr=None):
+    def __call__(self, stream, x_ptr=None, y_ptr=None, flag_ptr=None):
+        if flag_ptr is not None:
+            self._epi.domain_flag = flag_ptr       # the caller's domain-flag word of THIS batch (engine "auto" mode)
         rc = self._fn(self._h, ctypes.c_void_p(x_ptr or self._x), *self._mid, ctypes.c_void_p(y_ptr or self._y),
                       ctypes.c_void_p(stream))
         if rc != QNN_OK:

@@ -134,6 +134,7 @@ struct EpiArgs {
     float trick_c, trick_s;    // output-side identity trick of the reference ("faithful" mode); trick_s == 0: off
     const float* fold_a;       // qnn_fold_t of this layer + epilogue (qnn_fold.h): per-channel slope, or nullptr = evaluate
     const int32_t* fold_b;     // the float32 chain; per-channel accumulator offset in units of acc / 256
+    uint32_t* dom_flag;        // the caller's domain-flag word for this call (qnn_epilogue_t.domain_flag) or nullptr = the handle's
     const float* fold_c;       // "bits" form of the fold (fold_b carries 0x4B400000, u = fma(as_float(acc), a, c)), or nullptr
 };
 

@@ -1139,6 +1139,7 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
     e->fold_a = nullptr;
     e->fold_b = nullptr;
     e->fold_c = nullptr;
+    e->dom_flag = epi->domain_flag;
     if (epi->fold) {
         // the fold must have been prepared for exactly this layer and epilogue; a handle whose sweep found a differing
         // point on some channel (folded < cout) is accepted and ignored: the kernels evaluate the float32 chain
@@ -1257,7 +1258,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     if (x_store == QNN_STORE_U8) e.scale = 255.0f * (float)(1 << w->wshift);   // the divisor D of the affine map
     // a restricted-domain kernel (first_fixed) saw a value outside its domain in an earlier launch of this layer, and
     // the flag has reached the host: report it now (qnn_weights_check is the synchronising form)
-    if (w->h_flag && *(volatile uint32_t*)w->h_flag) {
+    if (!epi->domain_flag && w->h_flag && *(volatile uint32_t*)w->h_flag) {
         *(volatile uint32_t*)w->h_flag = 0;
         qnn_set_error("conv_forward: an earlier launch of this layer's restricted-domain kernel met inputs outside its "
                       "domain (first_fixed: [0, 1]; first_image: image bytes / 255); its outputs are unspecified.  Use the "

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_fixed(ConvGeom g, EpiArgs
 int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                                hipStream_t s) {
     if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.cin != 3 || g.cout != 64 || e.res) return 1;
-    if ((g.W % 16) != 0 || (g.H % 2) != 0 || !w->d_wq || !w->d_flag) return 1;    // no flag word, no restricted-domain kernel
+    if ((g.W % 16) != 0 || (g.H % 2) != 0 || !w->d_wq || !(e.dom_flag ? e.dom_flag : w->d_flag)) return 1;    // no flag word, no restricted-domain kernel
     // weight codes = value * 2^wshift: binary (+-1, H = 1) or quantized to <= 4 bits (|code| <= 8)
     if (w->wkind == QNN_W_BINARY ? (w->H != 1.0f || w->wshift != 0)
                                : (w->wkind != QNN_W_QUANT || w->wshift < 1 || w->wshift > 3)) return 1;
@@ -292,7 +292,7 @@ int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* 
 #define FIXED_LAUNCH(OUT_, POOL_, BIN_)                                                                                   \
     hipLaunchKernelGGL((k_conv_first_fixed<OUT_, POOL_, BIN_>), grid, block, lds, s, g, e, (const float*)x, w->d_wq, y,    \
                        (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch), best_rc, \
-                       (uint32_t)img_x, wscale, vscale, 1.0f / vscale, w->d_flag)
+                       (uint32_t)img_x, wscale, vscale, 1.0f / vscale, (e.dom_flag ? e.dom_flag : w->d_flag))
     if (!fused) FIXED_LAUNCH(QNN_STORE_F32, 1, false);
     else if (e.fn == QNN_FN_BINARY_TANH) FIXED_LAUNCH(QNN_STORE_I4, 2, true);
     else FIXED_LAUNCH(QNN_STORE_I4, 2, false);

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, (NBLK == 1 ? 6 : 3)) void k_conv_first_u8_full
 // fused pipeline form (pool 2, int4 codes out) or float32 output without pooling.
 int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                             hipStream_t s, bool f32in) {
-    if (f32in && !w->d_flag) return 1;                           // no flag word, no restricted-domain kernel
+    if (f32in && !(e.dom_flag ? e.dom_flag : w->d_flag)) return 1;                           // no flag word, no restricted-domain kernel
     if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.cin != 3 || e.res) return 1;
     if ((g.W % 16) != 0 || (g.H % 2) != 0 || !w->d_wq) return 1;
     // weight codes = value * 2^wshift: binary (+-1, H = 1) or quantized (pooled form: <= 7 bits, |code| <= 64 -- the negated
@@ -566,7 +566,7 @@ int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, 
 #define U8_FULL(OUT_, NB_, BIN_, F32_)                                                                                      \
         hipLaunchKernelGGL((k_conv_first_u8_full<OUT_, NB_, BIN_, F32_>), fgrid, block, lds, s, g, e, x, w->d_wq, y,         \
                            (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),       \
-                           best_rc, (uint32_t)img_x, wscale, D, w->d_flag)
+                           best_rc, (uint32_t)img_x, wscale, D, (e.dom_flag ? e.dom_flag : w->d_flag))
 #define U8_FULL_B(OUT_, NB_)                                                                                                \
         do {                                                                                                               \
             if (bin) { if (f32in) U8_FULL(OUT_, NB_, true, true); else U8_FULL(OUT_, NB_, true, false); }                   \
@@ -583,11 +583,11 @@ int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, 
         if (f32in)                                                                                                         \
             hipLaunchKernelGGL((k_conv_first_u8<OUT_, POOL_, BIN_, true>), grid, block, lds, s, g, e, x, w->d_wq, y,        \
                                (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),  \
-                               best_rc, (uint32_t)img_x, wscale, D, w->d_flag);                                            \
+                               best_rc, (uint32_t)img_x, wscale, D, (e.dom_flag ? e.dom_flag : w->d_flag));                                            \
         else                                                                                                               \
             hipLaunchKernelGGL((k_conv_first_u8<OUT_, POOL_, BIN_, false>), grid, block, lds, s, g, e, x, w->d_wq, y,       \
                                (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),  \
-                               best_rc, (uint32_t)img_x, wscale, D, w->d_flag);                                            \
+                               best_rc, (uint32_t)img_x, wscale, D, (e.dom_flag ? e.dom_flag : w->d_flag));                                            \
     } while (0)
     if (!fused) U8_LAUNCH(QNN_STORE_F32, 1, false);
     else if (e.fn == QNN_FN_BINARY_TANH) U8_LAUNCH(QNN_STORE_I4, 2, true);

@@ -110,25 +110,34 @@ class FusedModel:
     forward(x) takes the images either as uint8 NHWC, the dataset's own bytes (value = code / 255,
     utils/load_data.py:40: the typed QNN_STORE_U8 entry of the C ABI, an exact integer first layer), or as float32
     NHWC, where `first_layer` picks the kernel:
-      "exact"  any float32 values: the float32 FMA chain the oracle evaluates (default);
+      "auto"   any float32 values (default): a batch is first run on the byte kernel of "image" with a domain-flag word
+               of its own (qnn_epilogue_t.domain_flag); a batch that turns out NOT to be image bytes / 255 is recomputed,
+               in-process, on the exact kernel.  Like the reference's call() (quantized_layers.py:164-194) it accepts
+               every float tensor; dataset images (utils/load_data.py:40) take the fast kernel.
+      "exact"  any float32 values: the float32 FMA chain the oracle evaluates;
       "image"  float32 values that are image bytes / 255: recognised as bytes, computed like the uint8 entry;
       "fixed"  float32 values in [0, 1]: fixed point at 2^-23.
     "image" and "fixed" have restricted domains; a value outside raises the layer's domain flag, which surfaces as
     QnnError from check_domain() (or from the next forward once the host has seen it) -- never silently."""
 
     # how float32 images are declared to the C ABI: a typed entry per call, no process-wide switch is touched
-    FIRST_LAYER_STORE = {"exact": _abi.STORE_F32, "image": _abi.STORE_F32_IMAGE, "fixed": _abi.STORE_F32_UNIT}
+    FIRST_LAYER_STORE = {"exact": _abi.STORE_F32, "image": _abi.STORE_F32_IMAGE, "fixed": _abi.STORE_F32_UNIT,
+                         "auto": _abi.STORE_F32_IMAGE}
 
-    def __init__(self, spec, device="cuda", first_layer="exact", trick=None):
+    def __init__(self, spec, device="cuda", first_layer="auto", trick=None):
         """trick: None = the reference's lr-multiplier identity trick is the identity ("exact" mode, the default), or
         "nep50" / "legacy" = its OUTPUT side (binary_layers.py:175-176) is replayed in float32 behind every low-bit
         conv with the constants the reference forms under that numpy promotion rule (qnn_abi.h, trick_c / trick_s):
         reproduces the reference's rounding noise on 8-bit activation grids at the price of the VALU kernel family."""
         if first_layer not in self.FIRST_LAYER_STORE:
-            raise ValueError("first_layer must be 'exact', 'image' or 'fixed', got %r" % (first_layer,))
+            raise ValueError("first_layer must be 'auto', 'exact', 'image' or 'fixed', got %r" % (first_layer,))
         if trick not in (None, "nep50", "legacy"):
             raise ValueError("trick must be None, 'nep50' or 'legacy', got %r" % (trick,))
+        if first_layer == "auto" and trick is not None:
+            first_layer = "exact"            # the faithful output-side trick lives in the VALU kernel family only
         self.first_layer = first_layer
+        self._flag = None                    # "auto": this model's own domain-flag word (eager forwards, captured graphs)
+        self._exact_now = False              # "auto": the batch being recomputed takes the exact kernel
         self.device = torch.device(device)
         self.fuse_head = True                # conv group + Flatten + Dense in one launch where the library has the kernel
         self._head_no = {}                   # (H, W) of inputs the library has no fused head kernel for
@@ -265,16 +274,29 @@ class FusedModel:
             return _abi.dense(st["w"], cur, st["x_store"], st["x_bits"], N, st["inv"], st["shift"],
                               st["fn"], st["act_bits"], st["out_store"], out=out), H, W
         u8 = si == 0 and cur.dtype == torch.uint8
+        if u8 and st["trick"] is not None:
+            #  never drop the faithful trick silently: the uint8 entry has no output-side trick
+            raise _abi.QnnError("FusedModel: trick=%r cannot be combined with uint8 images (the QNN_STORE_U8 entry has no "
+                                "output-side trick); pass float32 images" % (st["trick"],))
         x_store = _abi.STORE_U8 if u8 else self._x_store(si)
+        flag = self._own_flag() if (si == 0 and not u8 and self._auto_now()) else None
         return _abi.conv2d(st["w"], cur, x_store, st["x_bits"], N, H, W, st["inv"],
                            st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"], out=out,
-                           trick=None if u8 else st["trick"])
+                           trick=st["trick"], domain_flag=flag)
+
+    def _auto_now(self):
+        return self.first_layer == "auto" and not self._exact_now and self.steps[0]["x_store"] == _abi.STORE_F32
+
+    def _own_flag(self):
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._flag
 
     def _x_store(self, si):
         """Input store of step si for float32 / packed inputs (the first step carries the declared image domain)."""
         st = self.steps[si]
         if si == 0 and st["x_store"] == _abi.STORE_F32:
-            return self.FIRST_LAYER_STORE[self.first_layer]
+            return _abi.STORE_F32 if self._exact_now else self.FIRST_LAYER_STORE[self.first_layer]
         return st["x_store"]
 
     def bind(self, example):
@@ -305,10 +327,15 @@ class FusedModel:
                                         trick=None if (u8 and si == 0) else st["trick"]))
             cur, H, W = out, H1, W1
         last = len(bound) - 1
+        own = self._own_flag().data_ptr() if (self._auto_now() and not u8) else None
 
-        def plan(stream, x_ptr, y_ptr):
+        def plan(stream, x_ptr, y_ptr, flag_ptr=None):
+            """flag_ptr ("auto" first layer): device address of THIS batch's domain-flag word (default: the model's)."""
             for i, b in enumerate(bound):
-                b(stream, x_ptr if i == 0 else None, y_ptr if i == last else None)
+                if i == 0 and own is not None:
+                    b(stream, x_ptr, y_ptr if i == last else None, flag_ptr or own)
+                else:
+                    b(stream, x_ptr if i == 0 else None, y_ptr if i == last else None)
         return plan, tuple(cur.shape), cur.dtype
 
     def forward_from(self, s0, cur, N, H, W, out=None):
@@ -339,11 +366,43 @@ class FusedModel:
         if u8 and (self.steps[0]["kind"] != "conv" or self.steps[0]["w"].wkind == _abi.W_FLOAT):
             raise _abi.QnnError("FusedModel.forward: uint8 images need a low-bit convolution as the first layer")
         N, H, W, _ = x.shape
-        return self.forward_from(0, x, N, H, W)
+        y = self.forward_from(0, x, N, H, W)
+        if not u8 and self._auto_now() and not torch.cuda.is_current_stream_capturing():
+            # "auto": the batch ran on the byte kernel with this model's flag word; not image bytes / 255 -> the exact kernel
+            if int(self._own_flag().item()) != 0:
+                self._flag.zero_()
+                y = self.forward_exact(x)
+        return y
+
+    def forward_exact(self, x, out=None):
+        """The forward with the exact float32 first layer, whatever `first_layer` says (what "auto" falls back to)."""
+        x = _abi.require_cuda(x, "FusedModel.forward_exact")
+        N, H, W, _ = x.shape
+        self._exact_now = True
+        try:
+            return self.forward_from(0, x, N, H, W, out=out)
+        finally:
+            self._exact_now = False
+
+    def take_flag(self):
+        """"auto": synchronise, return True and clear if this model's own flag word is raised (a captured graph or a bench
+        replay met a batch that is not image bytes / 255)."""
+        if self._flag is None:
+            return False
+        raised = int(self._flag.item()) != 0
+        if raised:
+            self._flag.zero_()
+        return raised
 
     def check_domain(self):
         """Synchronise the current stream and raise QnnError if a restricted-domain first layer ("fixed", "image") met
-        an input outside its domain since the last check (qnn_weights_check).  A no-op for the exact and uint8 entries."""
+        an input outside its domain since the last check (qnn_weights_check).  "auto": raises only for replays nobody
+        recomputed (hipGraph replays outside engine.Pipelined.forward).  A no-op for the exact and uint8 entries."""
+        if self.first_layer == "auto":
+            if self.take_flag():
+                raise _abi.QnnError("FusedModel: a replayed batch was not image bytes / 255 and has not been recomputed on "
+                                    "the exact first layer (run it through forward() / engine.Pipelined.forward())")
+            return
         self.steps[0]["w"].check()
 
     __call__ = forward
@@ -550,16 +609,19 @@ class ResidualFusedModel:
     float32 torch ops on unpacked tensors.
     """
 
-    def __init__(self, spec, device="cuda", first_layer="exact", fold=True):
+    def __init__(self, spec, device="cuda", first_layer="auto", fold=True):
         """first_layer: kernel for float32 images in front of the first (3-channel) conv, as engine.FusedModel:
-        "exact" (default) or "image" (float32 bytes / 255 recognised as bytes; domain flag -> check_domain()).  uint8
+        "auto" (default: byte kernel with a per-batch domain flag, a batch that is not bytes / 255 is recomputed on the
+        exact kernel), "exact" or "image" (float32 bytes / 255 recognised as bytes; domain flag -> check_domain()).  uint8
         images always take the typed QNN_STORE_U8 entry.
         fold: True (default) = every int4 -> int4 layer gets its epilogue folded to integer thresholds the first time it
         runs (qnn_fold_prepare: proven equal to the float32 chain on the layer's whole accumulator domain; layers the
         library cannot fold exactly keep the chain); False = always the float32 chain.  Same bits either way."""
-        if first_layer not in ("exact", "image"):
-            raise ValueError("first_layer must be 'exact' or 'image', got %r" % (first_layer,))
+        if first_layer not in ("auto", "exact", "image"):
+            raise ValueError("first_layer must be 'auto', 'exact' or 'image', got %r" % (first_layer,))
         self.first_layer = first_layer
+        self._flag = None
+        self._exact_now = False
         self.fold = bool(fold)
         self._folds = {}                     # (conv, bn, shortcut kind, ...) -> _abi.Fold or None
         self.device = torch.device(device)
@@ -633,14 +695,49 @@ class ResidualFusedModel:
                     out.append(self.spec[ci])
         return out
 
+    def _own_flag(self):
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._flag
+
+    def take_flag(self):
+        if self._flag is None:
+            return False
+        raised = int(self._flag.item()) != 0
+        if raised:
+            self._flag.zero_()
+        return raised
+
     def check_domain(self):
-        """Synchronise and raise QnnError if the "image" first layer met a float32 input that is not a byte / 255."""
+        """Synchronise and raise QnnError if the "image" first layer met a float32 input that is not a byte / 255
+        ("auto": only for replays nobody recomputed, as FusedModel.check_domain)."""
+        if self.first_layer == "auto":
+            if self.take_flag():
+                raise _abi.QnnError("ResidualFusedModel: a replayed batch was not image bytes / 255 and has not been "
+                                    "recomputed on the exact first layer")
+            return
         for w in self._w.values():
             if w.shape[2] <= 4 and w.store == _abi.STORE_F32:
                 w.check()
 
+    def forward_exact(self, x):
+        self._exact_now = True
+        try:
+            return self._forward(x)
+        finally:
+            self._exact_now = False
+
     # ---- evaluation --------------------------------------------------------------
     def forward(self, x):
+        y = self._forward(x)
+        if self.first_layer == "auto" and not self._exact_now and isinstance(x, torch.Tensor) and x.dtype == torch.float32 \
+                and self._flag is not None and not torch.cuda.is_current_stream_capturing():
+            if int(self._flag.item()) != 0:          # not image bytes / 255: recompute on the exact first layer
+                self._flag.zero_()
+                y = self.forward_exact(x)
+        return y
+
+    def _forward(self, x):
         x = (_abi.require_cuda_u8(x, "ResidualFusedModel.forward")
              if isinstance(x, torch.Tensor) and x.dtype == torch.uint8
              else _abi.require_cuda(x, "ResidualFusedModel.forward"))
@@ -677,8 +774,13 @@ class ResidualFusedModel:
                 if src.dtype == torch.uint8:     # the images as bytes: typed QNN_STORE_U8 entry
                     xs = _abi.STORE_U8
 
-            if self.first_layer == "image" and xs == _abi.STORE_F32 and src is memo["input"]:
-                xs = _abi.STORE_F32_IMAGE        # the images: declared as bytes / 255 for this call (typed entry)
+            dflag = None
+            if xs == _abi.STORE_F32 and src is memo["input"] and not self._exact_now:
+                if self.first_layer == "image":
+                    xs = _abi.STORE_F32_IMAGE    # the images: declared as bytes / 255 for this call (typed entry)
+                elif self.first_layer == "auto":
+                    xs = _abi.STORE_F32_IMAGE    # ... with this model's own flag word: forward() recomputes a flagged batch
+                    dflag = self._own_flag()
 
             fold = None
             if self.fold and xs == _abi.STORE_I4 and out_store == _abi.STORE_I4 and fn == _abi.FN_QUANTIZED_TANH and ab == 4 \
@@ -690,7 +792,8 @@ class ResidualFusedModel:
                 fold = self._folds[fkey]
 
             def launch():
-                return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, fold=fold, **rkw)
+                return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, fold=fold, domain_flag=dflag,
+                                   **rkw)
 
             y, Ho, Wo = launch()
             if self.kernel_log is not None:
@@ -888,24 +991,46 @@ class Pipelined:
         self.model, self.nlanes, self.batch_size = model, int(lanes), int(batch_size)
         self._lanes = {}                     # (batch shape, dtype) -> list of lane dicts
 
-    def _capture(self, example, slots=1):
-        key = (tuple(example.shape), example.dtype, slots)
+    def _auto(self, example):
+        """True if batches like `example` run the model's "auto" first layer (float32 images, per-batch domain flags)."""
+        return getattr(self.model, "first_layer", None) == "auto" and example.dtype == torch.float32
+
+    def _capture(self, example, slots=1, inputs=1):
+        key = (tuple(example.shape), example.dtype, slots, inputs)
         if key in self._lanes:
             return self._lanes[key]
         lanes = []
         cur = torch.cuda.current_stream()
         direct = slots > 1 and isinstance(self.model, FusedModel) and not self.model.steps[-1]["softmax"]
+        auto = self._auto(example)
+        model_flag = getattr(self.model, "_flag", None)
         for _ in range(self.nlanes):
             xs = torch.empty_like(example)
             xs.copy_(example)
             side = torch.cuda.Stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                for _ in range(2):           # warm-up outside capture: lazy initialisation, allocator pools
+                for _ in range(2):           # warm-up outside capture: lazy initialisation, allocator pools, folds
                     y0 = self.model(xs)
             cur.wait_stream(side)
             lane = dict(stream=torch.cuda.Stream(), x=xs)
-            if slots == 1:
+            if auto:
+                # "auto" first layer: every lane owns the domain-flag word its graphs write (the model's own word while
+                # the lane is captured); forward() copies it out per batch, bench.py reads it after its timed region
+                lane["flag"] = torch.zeros(1, dtype=torch.int32, device=example.device)
+                self.model._flag = lane["flag"]
+            if slots == 1 and inputs > 1:
+                # `inputs` static input buffers per lane, one graph each: a replay loop that rotates them streams its
+                # images from HBM instead of re-reading one batch out of the 256 MB Infinity Cache (bench.py)
+                lane.update(xs=[xs] + [xs.clone() for _ in range(inputs - 1)], graphs=[], ys=[])
+                for xi in lane["xs"]:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        yi = self.model(xi)
+                    lane["graphs"].append(g)
+                    lane["ys"].append(yi)
+                lane.update(graph=lane["graphs"][0], y=lane["ys"][0])
+            elif slots == 1:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     ys = self.model(xs)
@@ -918,25 +1043,45 @@ class Pipelined:
                 ring = torch.zeros((slots * B,) + tuple(y0.shape[1:]), dtype=y0.dtype, device=y0.device)
                 lane.update(ring=ring, direct=direct, graphs=[])
                 N, H, W, _ = example.shape
+                # `inputs` static input buffers: slot j's graph reads buffer j % inputs (HBM-streaming replays, as above)
+                lane["xs"] = [xs] + [xs.clone() for _ in range(min(inputs, slots if direct else 1) - 1)]
                 for j in range(slots if direct else 1):
+                    xi = lane["xs"][j % len(lane["xs"])]
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         if direct:
-                            ys = self.model.forward_from(0, xs, N, H, W, out=ring[j * B:(j + 1) * B])
+                            ys = self.model.forward_from(0, xi, N, H, W, out=ring[j * B:(j + 1) * B])
                         else:
-                            ys = self.model(xs)
+                            ys = self.model(xi)
                     lane["graphs"].append(g)
                 lane.update(graph=lane["graphs"][0], y=ys)
             lanes.append(lane)
+        if auto:
+            self.model._flag = model_flag
         torch.cuda.synchronize()
         self._lanes[key] = lanes
         return lanes
 
-    def lanes_for(self, example, slots=1):
+    def lanes_for(self, example, slots=1, inputs=1):
         """The captured lanes for batches shaped like `example` (bench.py replays them directly).  slots > 1: every
         lane owns a ring of `slots` result blocks (`ring`, `graphs`, `direct`): replay `graphs[j]` to fill slot j when
-        `direct`, else replay `graph` and copy `y` into the slot."""
-        return self._capture(example, slots)
+        `direct`, else replay `graph` and copy `y` into the slot.  inputs > 1: `xs` = that many static input buffers per
+        lane (fill them with distinct batches), `graphs[j]` reads `xs[j % inputs]`.  "auto" first layer: `flag` = the
+        lane's domain-flag word (see lane_flags_raised)."""
+        return self._capture(example, slots, inputs)
+
+    def lane_flags_raised(self):
+        """Synchronise; True (and clear) if any captured lane's "auto" domain flag is raised: some replayed batch was not
+        image bytes / 255 and -- replayed by hand rather than through forward() -- has not been recomputed."""
+        torch.cuda.synchronize()
+        raised = False
+        for lanes in self._lanes.values():
+            for ln in (lanes or []):
+                f = ln.get("flag")
+                if f is not None and int(f.item()) != 0:
+                    f.zero_()
+                    raised = True
+        return raised
 
     def _bound_lanes(self, example):
         """Zero-copy form for FusedModel: per lane a bound launch plan (FusedModel.bind) with its own intermediate
@@ -961,16 +1106,30 @@ class Pipelined:
         m = self.model
         outs = torch.empty((x.shape[0],) + lanes[0]["yshape"][1:], dtype=lanes[0]["ydtype"], device=x.device)
         cur = torch.cuda.current_stream()
+        auto = self._auto(x)
+        flags = torch.zeros(nfull, dtype=torch.int32, device=x.device) if auto else None    # one domain-flag word per batch
         for ln in lanes:
             ln["stream"].wait_stream(cur)
         xb, xs = x.data_ptr(), B * x.stride(0) * x.element_size()
         yb, ys = outs.data_ptr(), B * outs.stride(0) * outs.element_size()
+        fb = flags.data_ptr() if auto else 0
         for i in range(nfull):
             ln = lanes[i % len(lanes)]
-            ln["plan"](ln["stream"].cuda_stream, xb + i * xs, yb + i * ys)
+            if auto:
+                ln["plan"](ln["stream"].cuda_stream, xb + i * xs, yb + i * ys, fb + 4 * i)
+            else:
+                ln["plan"](ln["stream"].cuda_stream, xb + i * xs, yb + i * ys)
         for ln in lanes:
             cur.wait_stream(ln["stream"])
+        if auto:
+            self._recompute_flagged(x, outs, B, flags)
         return outs
+
+    def _recompute_flagged(self, x, outs, B, flags):
+        """"auto" first layer: the batches whose domain flag is raised (not image bytes / 255) are recomputed on the exact
+        first layer, in place.  One host synchronisation (the flags are read)."""
+        for i in torch.nonzero(flags).flatten().tolist():
+            outs[i * B:(i + 1) * B] = self.model.forward_exact(x[i * B:(i + 1) * B])
 
     def forward(self, x):
         u8 = isinstance(x, torch.Tensor) and x.dtype == torch.uint8
@@ -986,6 +1145,8 @@ class Pipelined:
         elif nfull:
             lanes = self._capture(x[:B])
             outs = torch.empty((N,) + tuple(lanes[0]["y"].shape[1:]), dtype=lanes[0]["y"].dtype, device=x.device)
+            auto = self._auto(x)
+            flags = torch.zeros(nfull, dtype=torch.int32, device=x.device) if auto else None
             for ln in lanes:
                 ln["stream"].wait_stream(cur)          # x was produced on the caller's stream
             for i in range(nfull):
@@ -994,8 +1155,13 @@ class Pipelined:
                     ln["x"].copy_(x[i * B:(i + 1) * B], non_blocking=True)
                     ln["graph"].replay()
                     outs[i * B:(i + 1) * B].copy_(ln["y"], non_blocking=True)
+                    if auto:                           # this batch's flag out of the lane's word, which is cleared
+                        flags[i:i + 1].copy_(ln["flag"], non_blocking=True)
+                        ln["flag"].zero_()
             for ln in lanes:
                 cur.wait_stream(ln["stream"])
+            if auto:
+                self._recompute_flagged(x, outs, B, flags)
         if nfull * B < N:                              # ragged tail: eager, its own batch
             tail = self.model(x[nfull * B:])
             if outs is None:
@@ -1007,10 +1173,19 @@ class Pipelined:
     predict = forward
 
     def check_domain(self):
+        """Raise QnnError if a restricted-domain first layer met inputs outside its domain that nobody recomputed
+        ("image" / "fixed": the layer's flag; "auto": a lane flag left by hand-driven graph replays)."""
+        if self.lane_flags_raised():
+            raise _abi.QnnError("Pipelined: a replayed batch was not image bytes / 255 and has not been recomputed on the "
+                                "exact first layer (drive the batches through forward())")
         if hasattr(self.model, "check_domain"):
             self.model.check_domain()
         else:
             torch.cuda.synchronize()
+
+    def clear(self):
+        """Release every captured lane (graphs, static inputs, intermediate tensors)."""
+        self._lanes.clear()
 
 
 def _ok_lowbit(op):

@@ -272,17 +272,21 @@ class Model:
     test_resnet.py:63-81), reduced to the inference surface: predict / evaluate / summary /
     set of weights, executing on the fused GPU engines."""
 
-    def __init__(self, cf, spec, device="cuda", first_layer="exact", lanes=2):
-        """first_layer: kernel for float32 images ("exact" | "image" | "fixed", engine.FusedModel); uint8 images always
-        take the typed QNN_STORE_U8 entry.  lanes: batches kept in flight by predict() (engine.Pipelined)."""
+    def __init__(self, cf, spec, device="cuda", first_layer="auto", lanes=2):
+        """first_layer: kernel for float32 images ("auto" | "exact" | "image" | "fixed", engine.FusedModel; "auto", the
+        default, takes every float tensor like the reference's call(): the byte kernel where a batch is image bytes /
+        255, the exact kernel where it is not); uint8 images always take the typed QNN_STORE_U8 entry.  lanes: batches
+        kept in flight by predict() (engine.Pipelined)."""
         from . import engine, _abi
         self.cf, self.spec = cf, spec
         try:
             self.engine = engine.FusedModel(spec, device, first_layer=first_layer)     # chains (VGG)
         except _abi.NotFusable:                                     # residual / non-fusable topologies
-            self.engine = engine.ResidualFusedModel(spec, device, first_layer="image" if first_layer == "image" else "exact")
+            self.engine = engine.ResidualFusedModel(spec, device,
+                                                    first_layer=first_layer if first_layer in ("auto", "image") else "exact")
         self.layers = [op for op in spec if op["op"] in ("conv", "dense")]
         self.lanes = int(lanes)
+        self.upload_batches = 8              # predict() on a host array: batches uploaded (and resident) at a time
         self._pipes = {}
 
     def pipeline(self, batch_size=4096):
@@ -301,14 +305,25 @@ class Model:
         replayed from hipGraphs with `lanes` batches in flight; a ragged tail runs eagerly."""
         import torch
         resident = isinstance(x, torch.Tensor) and x.is_cuda
-        if not resident:
-            a = np.asarray(x)
-            a = np.ascontiguousarray(a if a.dtype == np.uint8 else a.astype(F32, copy=False))
-            x = torch.from_numpy(a).cuda()
-        y = self.pipeline(batch_size)(x)
-        if hasattr(self.engine, "check_domain") and getattr(self.engine, "first_layer", "exact") != "exact":
-            self.engine.check_domain()       # restricted-domain first layer: never hand out results unchecked
-        return y if resident else y.cpu().numpy()
+        restricted = hasattr(self.engine, "check_domain") and getattr(self.engine, "first_layer", "exact") in ("image", "fixed")
+        if resident:
+            y = self.pipeline(batch_size)(x)
+            if restricted:
+                self.engine.check_domain()   # restricted-domain first layer: never hand out results unchecked
+            return y
+        # host arrays are uploaded in chunks of a few batches (device memory bounded by the chunk, not by the dataset,
+        # like Keras' predict(batch_size)); whole batches per chunk, so batch-dependent activations see the same batches
+        a = np.asarray(x)
+        a = np.ascontiguousarray(a if a.dtype == np.uint8 else a.astype(F32, copy=False))
+        chunk = max(1, int(self.upload_batches)) * int(batch_size)
+        outs = []
+        for i in range(0, max(len(a), 1), chunk):
+            xc = torch.from_numpy(a[i:i + chunk]).cuda()
+            yc = self.pipeline(batch_size)(xc)
+            if restricted:
+                self.engine.check_domain()
+            outs.append(yc.cpu())
+        return torch.cat(outs).numpy()
 
     def evaluate(self, x, y, batch_size=4096):
         """Top-1 accuracy; y is one-hot (or +-1 hinge targets, utils/load_data.py:84-88) or class ids."""
@@ -355,7 +370,7 @@ class Model:
         print_fn("Total params: %d   engine: %s" % (self.count_params(), type(self.engine).__name__))
 
 
-def build_model(cf, seed=0, device="cuda", first_layer="exact", lanes=2):
+def build_model(cf, seed=0, device="cuda", first_layer="auto", lanes=2):
     """model_factory.py:18-72: config -> model (synthetic weights; use spec_from_keras_npz +
     Model(cf, spec) to run an imported checkpoint)."""
     return Model(cf, build_spec(cf, seed), device, first_layer=first_layer, lanes=lanes)

@@ -45,7 +45,7 @@ def test_activation_range_probe_matches_the_oracle():
     from oracle import qnn_oracle as O
     cf = nets.Config(network_type="full-qnn", architecture="RESNET", dataset="CIFAR-10", dim=32, channels=3,
                      wbits=4, abits=4, nres=1, pfilt=1)
-    model = nets.build_model(cf, seed=5)
+    model = nets.build_model(cf, seed=5, first_layer="exact")
     x = nets.synthetic_images(cf, 6, seed=9)
     convs = [i for i, op in enumerate(model.spec) if op["op"] == "conv"]
     number = 3

@@ -145,7 +145,7 @@ def test_headline_network_with_the_fixed_point_first_layer(fixed_first_layer):
     spec = nets.build_spec(cf, nets.SEED_BASE + 2)
     rng = np.random.default_rng(77)
     x = (rng.integers(0, 256, (256, 32, 32, 3)).astype(F32) / F32(255)).astype(F32)
-    model = engine.FusedModel(spec)
+    model = engine.FusedModel(spec, first_layer="exact")
     model.kernel_log = []
     got = host(model(torch.from_numpy(x).cuda()))
     assert model.kernel_log[0] == "mfma_i8x3_first_fixed"

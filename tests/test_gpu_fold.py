@@ -170,12 +170,12 @@ def test_residual_engine_with_and_without_folds(nres):
     spec = nets.build_spec(cf, 5)[:-1]
     x = nets.synthetic_images(cf, 3, 5)
     want = O.run_spec(spec, x, float_conv="device")
-    m = engine.ResidualFusedModel(spec)
+    m = engine.ResidualFusedModel(spec, first_layer="exact")
     got = host(m(dev(x)))
     np.testing.assert_array_equal(got, want)
     folds = [f for f in m._folds.values() if f is not None]
     assert len(folds) >= 6 * nres - 2 and sum(f.usable for f in folds) >= len(folds) - 2, \
         [(f.folded, f.channels) for f in folds]
-    m0 = engine.ResidualFusedModel(spec, fold=False)
+    m0 = engine.ResidualFusedModel(spec, fold=False, first_layer="exact")
     np.testing.assert_array_equal(host(m0(dev(x))), want)
     assert not m0._folds

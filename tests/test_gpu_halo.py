@@ -161,7 +161,7 @@ def test_headline_network_same_logits_with_and_without_the_halo_kernel():
     for halo in (1, 0):
         _abi.set_option("halo", halo)
         try:
-            m = engine.FusedModel(spec)
+            m = engine.FusedModel(spec, first_layer="exact")
             m.kernel_log = []
             outs[halo] = host(m(dev(x)))
             used = any("halo" in k for k in m.kernel_log)

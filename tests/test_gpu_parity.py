@@ -455,7 +455,7 @@ def test_vgg_configs_end_to_end(idx, impl):
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     x = nets.synthetic_images(cf, 6, nets.SEED_BASE + idx)
     want = O.run_spec(spec, x, float_conv="device")
-    fused = engine.FusedModel(spec)
+    fused = engine.FusedModel(spec, first_layer="exact")
     got = host(fused(dev(x)))
     np.testing.assert_array_equal(got, want)
     graph = host(engine.GraphModel(spec)(dev(x)))
@@ -481,7 +481,7 @@ def test_flatten_of_channels_that_do_not_fill_packed_words(nt, wb, ab, nfc):
     x = nets.synthetic_images(cf, 3, 5)
     want = O.run_spec(spec, x, float_conv="device")
     try:
-        fused = engine.FusedModel(spec)
+        fused = engine.FusedModel(spec, first_layer="exact")
     except _abi.NotFusable:
         assert nfc % 4 != 0                       # no packed storage whose words the channels fill
         fused = None
@@ -489,7 +489,7 @@ def test_flatten_of_channels_that_do_not_fill_packed_words(nt, wb, ab, nfc):
         last_conv = [st for st in fused.steps if st["kind"] == "conv"][-1]
         assert nfc % _abi.per_word(last_conv["out_store"]) == 0
         np.testing.assert_array_equal(host(fused(dev(x))), want)
-    model = nets.Model(cf, spec)
+    model = nets.Model(cf, spec, first_layer="exact")
     assert type(model.engine).__name__ == ("FusedModel" if fused is not None else "ResidualFusedModel")
     np.testing.assert_array_equal(model.predict(x), want)
 
@@ -502,7 +502,7 @@ def test_model_does_not_mask_real_errors_as_not_fusable(monkeypatch):
         raise _abi.QnnError("prepack failed")
     monkeypatch.setattr(engine, "_prepack", boom)
     with pytest.raises(_abi.QnnError, match="prepack failed"):
-        nets.Model(cf, spec)
+        nets.Model(cf, spec, first_layer="exact")
 
 
 def test_one_bit_layers_on_the_matrix_pipe():
@@ -515,13 +515,13 @@ def test_one_bit_layers_on_the_matrix_pipe():
     want = O.run_spec(spec, x, float_conv="device")
     try:
         _abi.set_conv_impl(_abi.IMPL_AUTO)
-        fused = engine.FusedModel(spec)
+        fused = engine.FusedModel(spec, first_layer="exact")
         stores = [st["x_store"] for st in fused.steps]
         assert _abi.STORE_I4 in stores and stores[0] == _abi.STORE_F32, stores
         got = host(fused(dev(x)))
         np.testing.assert_array_equal(got, want)
         _abi.set_conv_impl(_abi.IMPL_VALU)
-        fused_v = engine.FusedModel(spec)
+        fused_v = engine.FusedModel(spec, first_layer="exact")
         assert _abi.STORE_I4 not in [st["x_store"] for st in fused_v.steps]
         np.testing.assert_array_equal(host(fused_v(dev(x))), want)
     finally:
@@ -595,7 +595,7 @@ def test_vgg_large_8bit_small_batch(impl):
     spec = nets.build_spec(cf, nets.SEED_BASE + 3)
     x = nets.synthetic_images(cf, 2, nets.SEED_BASE + 3)
     want = O.run_spec(spec, x, float_conv="device")
-    got = host(engine.FusedModel(spec)(dev(x)))
+    got = host(engine.FusedModel(spec, first_layer="exact")(dev(x)))
     np.testing.assert_array_equal(got, want)
 
 
@@ -644,7 +644,7 @@ def test_residual_fused_model(nt, wb, ab, nres):
     spec = nets.build_spec(cf, 77)
     x = nets.synthetic_images(cf, 3, 77)
     want = O.run_spec(spec, x, float_conv="device")
-    m = engine.ResidualFusedModel(spec)
+    m = engine.ResidualFusedModel(spec, first_layer="exact")
     m.kernel_log = []
     got = host(m(dev(x)))
     np.testing.assert_allclose(got, want, atol=2e-5 if nt == "qnn" else 1e-6)
@@ -652,7 +652,7 @@ def test_residual_fused_model(nt, wb, ab, nres):
         # logits before the softmax are bit-exact, and nothing fell back to the generic kernel
         logits_name = [op["dst"] for op in spec if op["op"] == "dense"][0]
         env = O.run_spec(spec, x, float_conv="device", return_all=True)
-        np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec[:-1])(dev(x))), env[logits_name])
+        np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec[:-1], first_layer="exact")(dev(x))), env[logits_name])
         assert "generic" not in m.kernel_log, m.kernel_log
         assert len(m.kernel_log) == sum(op["op"] == "conv" for op in spec)
         if (nt, wb, ab) == ("full-qnn", 4, 4):
@@ -676,7 +676,7 @@ def test_residual_fused_model_at_imagenet_geometry():
     spec = nets.build_spec(cf, 11)[:-1]                     # logits
     x = nets.synthetic_images(cf, 2, 12)
     want = O.run_spec(spec, x, float_conv="device")
-    m = engine.ResidualFusedModel(spec)
+    m = engine.ResidualFusedModel(spec, first_layer="exact")
     m.kernel_log = []
     got = host(m(dev(x)))
     np.testing.assert_array_equal(got, want)
@@ -684,7 +684,7 @@ def test_residual_fused_model_at_imagenet_geometry():
         assert k in m.kernel_log or k + "_lds" in m.kernel_log, m.kernel_log
     _abi.set_option("strip64", 0)           # the LDS-weight kernel for the plain 64-channel layers: same logits
     try:
-        m3 = engine.ResidualFusedModel(spec)
+        m3 = engine.ResidualFusedModel(spec, first_layer="exact")
         m3.kernel_log = []
         np.testing.assert_array_equal(host(m3(dev(x))), want)
         assert "mfma_i4_areg64x64" in m3.kernel_log, m3.kernel_log
@@ -693,7 +693,7 @@ def test_residual_fused_model_at_imagenet_geometry():
     # the tile kernel (strip switch off) gives the same logits
     _abi.set_option("strip", 0)
     try:
-        m2 = engine.ResidualFusedModel(spec)
+        m2 = engine.ResidualFusedModel(spec, first_layer="exact")
         m2.kernel_log = []
         np.testing.assert_array_equal(host(m2(dev(x))), want)
         assert "mfma_i4_small_c16" in m2.kernel_log and not any(k.startswith("strip_i4_c16") for k in m2.kernel_log)
@@ -710,7 +710,7 @@ def test_config5_imagenet224_resnet_nres10_at_spec():
     assert sum(op["op"] == "conv" for op in spec) == 63
     x = nets.synthetic_images(cf, 1, 5)
     want = O.run_spec(spec[:-1], x, float_conv="device")
-    m = engine.ResidualFusedModel(spec[:-1])
+    m = engine.ResidualFusedModel(spec[:-1], first_layer="exact")
     m.kernel_log = []
     got = host(m(dev(x)))
     np.testing.assert_array_equal(got, want)
@@ -742,7 +742,7 @@ def test_residual_fused_model_on_trained_checkpoint(code, wb, ab):
     x = nets.synthetic_images(nets.Config(dim=32), 4, 12)
     env = O.run_spec(spec, x, float_conv="device", return_all=True)
     logits_name = [op["dst"] for op in spec if op["op"] == "dense"][0]
-    np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec[:-1])(dev(x))), env[logits_name])
+    np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec[:-1], first_layer="exact")(dev(x))), env[logits_name])
 
 
 @pytest.mark.parametrize("idx", [0, 1, 2])
@@ -750,7 +750,7 @@ def test_residual_fused_model_runs_vgg_too(idx):
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     x = nets.synthetic_images(cf, 4, 3)
-    np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec)(dev(x))),
+    np.testing.assert_array_equal(host(engine.ResidualFusedModel(spec, first_layer="exact")(dev(x))),
                                   O.run_spec(spec, x, float_conv="device"))
 
 
@@ -801,12 +801,12 @@ def test_ternary_networks(nt, arch):
         got = host(cls(spec)(dev(x)))
         np.testing.assert_allclose(got, want, atol=tol, err_msg=cls.__name__)
     if nt == "qtnn" and arch == "VGG":
-        np.testing.assert_array_equal(host(engine.FusedModel(spec)(dev(x))), want)
+        np.testing.assert_array_equal(host(engine.FusedModel(spec, first_layer="exact")(dev(x))), want)
 
 
 def test_build_model_predict_evaluate():
     cf = nets.baseline_config(2)
-    model = nets.build_model(cf, nets.SEED_BASE + 2)
+    model = nets.build_model(cf, nets.SEED_BASE + 2, first_layer="exact")
     assert type(model.engine).__name__ == "FusedModel" and model.count_params() > 80000
     x = nets.synthetic_images(cf, 10, 4)
     p = model.predict(x, batch_size=4)
@@ -816,7 +816,7 @@ def test_build_model_predict_evaluate():
     lines = []
     model.summary(lines.append)
     assert "Total params" in lines[-1]
-    rmodel = nets.build_model(nets.Config(architecture="RESNET", nres=1), 3)
+    rmodel = nets.build_model(nets.Config(architecture="RESNET", nres=1), 3, first_layer="exact")
     assert type(rmodel.engine).__name__ == "ResidualFusedModel"
 
 
@@ -839,7 +839,7 @@ def test_full_batch_properties(idx, impl):
         pytest.skip("VGG-large at batch 4096 on the VALU kernels alone takes minutes; covered at N=2")
     cf = nets.baseline_config(idx)
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
-    fused = engine.FusedModel(spec)
+    fused = engine.FusedModel(spec, first_layer="exact")
     N = 4096
     x = dev(nets.synthetic_images(cf, N, 99))
     y = fused(x)
@@ -861,7 +861,7 @@ def test_full_batch_properties_config5_residual_engine():
     engine (any sub-batch and any permutation give the same rows), finite outputs, head of the batch == oracle."""
     cf = nets.baseline_config(4)
     spec = nets.build_spec(cf, nets.SEED_BASE + 4)[:-1]           # logits
-    m = engine.ResidualFusedModel(spec)
+    m = engine.ResidualFusedModel(spec, first_layer="exact")
     N = 64
     x = dev(nets.synthetic_images(cf, N, 98))
     y = m(x)

@@ -128,7 +128,8 @@ def test_network_vs_reference(tag):
         engines.insert(0, engine.FusedModel)
     outs = {}
     for cls in engines:
-        outs[cls.__name__] = host(cls(spec)(dev(x)))
+        kw = {"first_layer": "exact"} if cls in (engine.FusedModel, engine.ResidualFusedModel) else {}
+        outs[cls.__name__] = host(cls(spec, **kw)(dev(x)))
     first = outs[engines[0].__name__]
     for name, got in outs.items():
         if cf.architecture == "VGG":

@@ -23,7 +23,7 @@ def test_full_tnn_forward_replays_from_a_hipgraph():
     """ternary_tanh = memset + reduction kernel + threshold kernel: all three must be capturable, and a replay on NEW
     input data must give the new data's result (a dangling host pointer in the graph would replay the old seed)."""
     cf, spec = _tnn()
-    m = engine.ResidualFusedModel(spec)
+    m = engine.ResidualFusedModel(spec, first_layer="exact")
     xs = [nets.synthetic_images(cf, 16, s) for s in (1, 2, 3)]
     static = dev(xs[0]).clone()
     side = torch.cuda.Stream()
@@ -59,7 +59,7 @@ def test_padded_shard_rows_stay_out_of_the_ternary_statistics():
     assert not np.array_equal(unhinted[:5], alone)
     # whole network through sharded_forward with world = 1 and a ragged total: identical to the plain forward
     cf, spec = _tnn()
-    m = engine.ResidualFusedModel(spec)
+    m = engine.ResidualFusedModel(spec, first_layer="exact")
     x = nets.synthetic_images(cf, 7, 4)
     np.testing.assert_array_equal(host(shard.sharded_forward(m, dev(x), 0, 1)), host(m(dev(x))))
 
@@ -113,13 +113,13 @@ def test_pipelined_first_layer_domain_is_checked_by_predict():
 def test_pipelined_residual_and_ternary_networks():
     cf = nets.Config(network_type="full-qnn", wbits=4, abits=4, architecture="RESNET", nres=1, dim=32)
     spec = nets.build_spec(cf, 3)
-    model = nets.Model(cf, spec)
+    model = nets.Model(cf, spec, first_layer="exact")
     assert type(model.engine).__name__ == "ResidualFusedModel"
     x = nets.synthetic_images(cf, 40, 9)
     eager = np.concatenate([host(model.engine(dev(x[i:i + 16]))) for i in range(0, 40, 16)])
     np.testing.assert_array_equal(model.predict(x, batch_size=16), eager)
     cf, spec = _tnn()
-    model = nets.Model(cf, spec)
+    model = nets.Model(cf, spec, first_layer="exact")
     x = nets.synthetic_images(cf, 48, 2)
     want = np.concatenate([O.run_spec(spec, x[i:i + 16], float_conv="device") for i in range(0, 48, 16)])
     np.testing.assert_array_equal(model.predict(x, batch_size=16), want)   # batch statistics per 16-image batch
@@ -142,7 +142,7 @@ def test_bench_default_line_carries_the_contract_and_the_round3_blocks():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in out, k
-    assert out["steps"] == 4 and out["n_gpus"] == 1 and out["config"]["first_layer"] == "image"
+    assert out["steps"] == 4 and out["n_gpus"] == 1 and out["config"]["first_layer"] == "auto"
     assert out["roofline"]["frac"] > 0 and out["roofline"]["bound"] in ("hbm", "mfma")
     assert set(out["first_layer_alternatives"]) == {"exact", "fixed", "u8"}
     assert all("value" in v for v in out["first_layer_alternatives"].values()), out["first_layer_alternatives"]
@@ -218,12 +218,12 @@ def test_fused_classifier_only_where_the_kernel_exists():
         cf = nets.baseline_config(idx)
         sp = nets.build_spec(cf, nets.SEED_BASE + idx)
         xi = nets.synthetic_images(cf, 9, 3)
-        m = engine.FusedModel(sp)
+        m = engine.FusedModel(sp, first_layer="exact")
         m.kernel_log = []
         got = host(m(dev(xi)))
         assert m.kernel_log[-2:] == ["mfma_i4_halo64x64+dense", "(fused into the conv)"], m.kernel_log
         np.testing.assert_array_equal(got, O.run_spec(sp, xi, float_conv="device"))
-        m2 = engine.FusedModel(sp)
+        m2 = engine.FusedModel(sp, first_layer="exact")
         m2.fuse_head = False
         m2.kernel_log = []
         np.testing.assert_array_equal(host(m2(dev(xi))), got)
@@ -231,7 +231,7 @@ def test_fused_classifier_only_where_the_kernel_exists():
     # VALU-only family: no matrix-pipe head
     _abi.set_conv_impl(_abi.IMPL_VALU)
     try:
-        m3 = engine.FusedModel(nets.build_spec(nets.baseline_config(2), 3))
+        m3 = engine.FusedModel(nets.build_spec(nets.baseline_config(2), 3), first_layer="exact")
         m3.kernel_log = []
         m3(dev(nets.synthetic_images(nets.baseline_config(2), 2, 1)))
         assert not any("+dense" in k for k in m3.kernel_log)

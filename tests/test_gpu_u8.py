@@ -155,7 +155,7 @@ def test_u8_rejects_what_it_cannot_compute():
     with pytest.raises(_abi.QnnError, match="residual"):
         _abi.conv2d(w, dev(xu8), _abi.STORE_U8, 0, 1, 16, 16, res=res, res_store=_abi.STORE_F32)
     with pytest.raises(TypeError, match="float32"):               # only float32 and uint8 images are typed entries
-        engine.FusedModel(nets.build_spec(nets.baseline_config(2), 1))(dev(xu8).to(torch.int32))
+        engine.FusedModel(nets.build_spec(nets.baseline_config(2), 1), first_layer="exact")(dev(xu8).to(torch.int32))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -170,14 +170,14 @@ def test_vgg_configs_on_uint8_images_bit_exact_vs_specification(idx):
     bn0["gamma"] = bn0["gamma"].copy()
     bn0["gamma"][::2] *= -1
     xu8 = nets.synthetic_images_u8(cf, 64, 99 + idx)
-    m = engine.FusedModel(spec)
+    m = engine.FusedModel(spec, first_layer="exact")
     m.kernel_log = []
     got = host(m(dev(xu8)))
     assert m.kernel_log[0] == ("mfma_i8_first_u8" if idx else "generic_u8")       # MNIST: one channel, 28 wide
     want = O.run_spec_u8(spec, xu8)
     np.testing.assert_array_equal(got, want)
     # the residual engine fuses the same conv + BN + activation group behind the bytes: same bits
-    got_r = host(engine.ResidualFusedModel(spec)(dev(xu8)))
+    got_r = host(engine.ResidualFusedModel(spec, first_layer="exact")(dev(xu8)))
     np.testing.assert_array_equal(got_r, want)
     # distance to the float32-input path on the same images: counted, not assumed
     x = (xu8.astype(F32) / F32(255)).astype(F32)
@@ -192,7 +192,7 @@ def test_resnet_on_uint8_images():
     cf = nets.Config(network_type="full-qnn", wbits=4, abits=4, architecture="RESNET", nres=1, dim=32)
     spec = nets.build_spec(cf, 3)[:-1]          # logits
     xu8 = nets.synthetic_images_u8(cf, 4, 3)
-    m = engine.ResidualFusedModel(spec)
+    m = engine.ResidualFusedModel(spec, first_layer="exact")
     m.kernel_log = []
     got = host(m(dev(xu8)))
     assert m.kernel_log[0] == "mfma_i8_first_u8"            # the stem on the byte kernel (un-pooled int4 output)
@@ -377,7 +377,7 @@ def test_fixed_point_first_layer_reports_inputs_outside_its_domain():
     m(dev(x))
     m.check_domain()
     # the exact kernel and the uint8 entry have no restricted domain
-    e = engine.FusedModel(spec)
+    e = engine.FusedModel(spec, first_layer="exact")
     e(dev(xb))
     e.check_domain()
 
@@ -408,7 +408,7 @@ def test_faithful_output_trick_reproduces_the_references_8bit_network_code_for_c
     assert flips == 0
     np.testing.assert_array_equal(got, y_ref)
     np.testing.assert_array_equal(got, O.run_spec(spec, x, mode="faithful_out", promotion=prom, float_conv="device"))
-    m = engine.FusedModel(spec, trick=prom)
+    m = engine.FusedModel(spec, trick=prom, first_layer="exact")
     m.kernel_log = []
     m(dev(x))
     assert not any(k.startswith("mfma_") or k.startswith("strip_") for k in m.kernel_log), m.kernel_log
@@ -478,7 +478,7 @@ def test_resnet_and_deep_vgg_take_the_byte_kernels():
     spec = nets.build_spec(cf, 3)[:-1]
     xu8 = nets.synthetic_images_u8(cf, 3, 3)
     want = O.run_spec_u8(spec, xu8)
-    m = engine.ResidualFusedModel(spec)
+    m = engine.ResidualFusedModel(spec, first_layer="exact")
     m.kernel_log = []
     np.testing.assert_array_equal(host(m(dev(xu8))), want)
     assert m.kernel_log[0] == "mfma_i8_first_u8", m.kernel_log[:2]
@@ -514,7 +514,7 @@ def test_full_batch_4096_on_the_byte_entries(idx):
     spec = nets.build_spec(cf, nets.SEED_BASE + idx)
     xu8 = nets.synthetic_images_u8(cf, 4096, 1234 + idx)
     x = (xu8.astype(F32) / F32(255)).astype(F32)
-    m = engine.FusedModel(spec)
+    m = engine.FusedModel(spec, first_layer="exact")
     mi = engine.FusedModel(spec, first_layer="image")
     y8 = host(m(dev(xu8)))
     yi = host(mi(dev(x)))
@@ -531,5 +531,5 @@ def test_full_batch_4096_on_the_byte_entries(idx):
     # pre-activation sits closer to a rounding threshold than the float32 chain's own error; one argmax of 4096 moves
     assert rows <= 100 and (y8.argmax(1) == ye.argmax(1)).mean() >= 0.999
     # the product call: same bits from predict() on numpy bytes
-    got = nets.Model(cf, spec).predict(xu8, batch_size=1024)
+    got = nets.Model(cf, spec, first_layer="exact").predict(xu8, batch_size=1024)
     np.testing.assert_array_equal(got, y8)
