@@ -847,6 +847,26 @@ def main_rank(args):
                 del mp, xb, yb
             except Exception as exc:  # pragma: no cover
                 out["model_predict_resident"] = {"error": str(exc)}
+        if args.workload == "vgg64_full_qnn_w4a4":
+            # the first layer's codes on THESE 4096 images against the reference's own first conv group, as generated by
+            # tests/golden/make_fixtures_from_reference.py and asserted on the GPU by tests/test_gpu_u8.py
+            try:
+                import numpy as _np
+                zf = _np.load(os.path.join(ROOT, "tests", "golden", "ref_bench_first.npz"))
+                bf = json.loads(bytes(zf["index_json"]).decode())["bench_first"]
+                own = "exact" if args.first_layer in ("exact", "fixed") else "u8"
+                out["first_layer_vs_reference"] = {
+                    "codes": bf["codes"], "entry": args.first_layer,
+                    "flips_vs_reference_numpy1_promotion": bf["flips_%s_vs_legacy" % own],
+                    "flips_vs_reference_numpy2_promotion": bf["flips_%s_vs_nep50" % own],
+                    "max_code_step": max(bf["maxabs_%s_vs_legacy" % own], bf["maxabs_%s_vs_nep50" % own]),
+                    "flips_exact_float32_chain_vs_reference": [bf["flips_exact_vs_legacy"], bf["flips_exact_vs_nep50"]],
+                    "flips_between_the_reference_promotions": bf["flips_nep50_vs_legacy"],
+                    "source": "tests/golden/ref_bench_first.npz (reference run on the benchmark's 4096 images, rank 0 batch); "
+                              "tests/test_gpu_u8.py::test_benchmark_first_layer_codes_against_the_reference_run asserts "
+                              "these counts on the GPU (fixed-point entry not covered)"}
+            except Exception as exc:  # pragma: no cover
+                out["first_layer_vs_reference"] = {"error": str(exc)}
         if world == 1 and not use_dist and not args.no_targets and args.workload == "vgg64_full_qnn_w4a4":
             try:
                 out["targets"] = measure_targets(torch, pkg, args)

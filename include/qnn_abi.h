@@ -72,10 +72,17 @@ extern "C" {
 /* float32 input WITH A DECLARED DOMAIN (first layer of a network, 3x3 on 3 channels; any other layer treats them as
  * QNN_STORE_F32).  The declaration selects the restricted-domain kernel for this call only -- no process-wide switch --
  * and a value outside the domain raises the layer's domain flag (qnn_weights_check):
- *   QNN_STORE_F32_IMAGE  the values are image bytes / 255 (utils/load_data.py:40): read as bytes, computed like QNN_STORE_U8
- *   QNN_STORE_F32_UNIT   the values lie in [0, 1]: fixed point at 2^-23 (see "first_fixed" below)
- * qnn_set_option("first_image" / "first_fixed", 1) makes the same declaration for every plain QNN_STORE_F32 call of the
- * process. */
+ *   QNN_STORE_F32_IMAGE  the values are image bytes / 255 (what utils/load_data.py:40 produces): a value x is read as the
+ *                        byte k = rint(255 x) when |255 x - k| <= 2^-15 (every float32 quotient k/255 passes) and raises
+ *                        the domain flag otherwise.  Result = the typed uint8 entry's (see qnn_conv2d_forward): exact
+ *                        integer sum, one float32 FMA.
+ *   QNN_STORE_F32_UNIT   the values lie in [0, 1] (64 filters of <= 4 bits): fixed point -- inputs rounded to 2^-23, exact
+ *                        int32 sums on the int8 matrix pipe, one rounding: within 27 * 2^-24 + half an ulp of the
+ *                        REAL-number convolution, hence inside the 1e-5 contract, but not the float32 FMA chain of the
+ *                        exact kernel -- activation codes whose pre-activation sits that close to a rounding threshold can
+ *                        differ from the oracle's.  Inputs outside [0, 1] (NaN included) are NOT silently saturated: the
+ *                        kernel raises the domain flag, see qnn_weights_check() / qnn_epilogue_t.domain_flag.
+ * (Round 4: the process-wide qnn_set_option() of ABI 3 is gone; these typed stores are the only way in.) */
 #define QNN_STORE_F32_IMAGE 17
 #define QNN_STORE_F32_UNIT  18
 
@@ -137,12 +144,31 @@ typedef struct qnn_epilogue {
     float trick_c;           /* output-side identity trick: 1 - 1/klm (ignored when trick_s == 0) */
     float trick_s;           /* klm, or 0 = the trick is the identity (default)                    */
     const qnn_fold_t* fold;  /* qnn_fold_prepare() of exactly this layer + epilogue, or NULL (ABI 4)  */
+    uint32_t flags;          /* QNN_EPI_* kernel-selection bits for THIS call (0 = the defaults); see below (ABI 4) */
     uint32_t* domain_flag;   /* DEVICE-visible word of the CALLER: a restricted-domain first-layer kernel
                               * (QNN_STORE_F32_IMAGE / _UNIT) that meets an input outside its domain stores a
                               * non-zero value there instead of raising the layer's own flag -- one word per
                               * batch in flight lets the caller recompute exactly the affected batch on the
                               * exact kernel (engine "auto" mode).  NULL = the handle's flag (ABI 4)          */
 } qnn_epilogue_t;
+
+/*
+ * qnn_epilogue_t.flags -- kernel selection for ONE call, for A/B measurements and tests.  Results are bit-identical
+ * under every combination; there is no process-wide switch (the library keeps no global state besides
+ * qnn_set_conv_impl's family preference).
+ *   QNN_EPI_NO_STRIP     3x3 stride-1 / -2 int4 layers with 16 / 32 / 64 channels: not the row-walking strip kernels
+ *                        (the tile kernels take them)
+ *   QNN_EPI_NO_STRIP64   only the 64-channel layers leave the strip kernel (the LDS-weight kernel takes them)
+ *   QNN_EPI_NO_HALO      pooled int4 layers with 64 input channels: per-tap operand fetch (k_conv_mfma_areg) instead of
+ *                        the receptive field staged once through LDS (k_conv_mfma_halo)
+ *   QNN_EPI_NO_LDS16     16 -> 16 channel layers with a fold: k_conv_strip instead of the LDS-staged k_conv_strip16_lds
+ * The restricted-domain first-layer kernels are selected by the TYPED input stores QNN_STORE_F32_IMAGE /
+ * QNN_STORE_F32_UNIT of the call (above), never by a switch.
+ */
+#define QNN_EPI_NO_STRIP    1u
+#define QNN_EPI_NO_STRIP64  2u
+#define QNN_EPI_NO_HALO     4u
+#define QNN_EPI_NO_LDS16    8u
 
 /* ---- library ------------------------------------------------------------ */
 int         qnn_version(void);
@@ -151,28 +177,6 @@ const char* qnn_last_error(void);
  * (XNOR+popcount / v_dot8 / v_dot4), 2 = prefer the int8 MFMA implicit GEMM.
  * Process-wide; results are bit-identical across families. */
 int         qnn_set_conv_impl(int impl);
-/* Kernel-selection switches for A/B measurements and tests; "strip" / "strip64" / "halo" give bit-identical results under
- * every setting, "first_fixed" does NOT (see below).
- *   "strip" (default 1): row-walking kernel for the 3x3 stride-1 int4 layers with 16 / 32 channels;
- *                        0 = the tile kernel (k_conv_mfma_small) takes them.
- *   "strip64" (default -1): the same kernel for 64-channel layers: 0 never (the LDS-weight kernel takes them), -1 / 1 always
- *                        (round 3: faster with and without a residual merge; pooled layers keep the LDS-weight kernel).
- *   "halo" (default 1): pooled int4 layers with 64 input channels whose pooled map tiles into 8 x 2 or 4 x 4 rectangles
- *                        stage each tile's receptive field once through LDS (k_conv_mfma_halo); 0 = the kernel that
- *                        fetches the pixels per tap (k_conv_mfma_areg) takes them.
- *   "first_fixed" (default 0): 1 = float-input 3x3 layers with 3 channels, 64 filters of <= 4 bits and inputs in [0, 1]
- *                        run in fixed point (inputs rounded to 2^-23, exact int32 sums on the int8 matrix pipe, one
- *                        rounding): within 27 * 2^-24 + half an ulp of the REAL-number convolution, hence inside the
- *                        1e-5 contract, but not the float32 FMA chain of the default kernel -- activation codes whose
- *                        pre-activation sits that close to a rounding threshold can differ from the oracle's.
- *                        Inputs outside [0, 1] (NaN included) are NOT silently saturated: the kernel raises the
- *                        layer's domain flag, see qnn_weights_check().
- *   "first_image" (default 0): 1 = the same layers, for float32 inputs that ARE image bytes / 255 (what
- *                        utils/load_data.py:40 produces), run on the QNN_STORE_U8 kernel: a value x is read as the byte
- *                        k = rint(255 x) when |255 x - k| <= 2^-15 (every float32 quotient k/255 passes) and raises the
- *                        domain flag otherwise.  Result = the typed uint8 entry's (see qnn_conv2d_forward): exact
- *                        integer sum, one float32 FMA.  Takes precedence over "first_fixed". */
-int         qnn_set_option(const char* key, int value);
 
 /* ---- elementwise activation clips on float32 tensors --------------------- */
 /* binary_ops.binary_tanh, layers/binary_ops.py:37-51 */

@@ -20,7 +20,7 @@ W_FLOAT, W_BINARY, W_QUANT, W_TERNARY = 0, 1, 2, 3
 FN_NONE, FN_BINARY_TANH, FN_QUANTIZED_TANH, FN_TERNARY_TANH, FN_GRID = 0, 1, 2, 3, 4
 
 EXPORTS = [
-    "qnn_version", "qnn_last_error", "qnn_last_kernel", "qnn_set_conv_impl", "qnn_set_option",
+    "qnn_version", "qnn_last_error", "qnn_last_kernel", "qnn_set_conv_impl",
     "qnn_binary_tanh_f32", "qnn_quantized_tanh_f32", "qnn_ternary_tanh_f32",
     "qnn_ternary_abs_sum_f32", "qnn_ternary_apply_f32",
     "qnn_packed_bytes", "qnn_pack_f32", "qnn_unpack_f32", "qnn_avgpool_packed_f32", "qnn_softmax_f32",
@@ -37,7 +37,7 @@ class Epilogue(ctypes.Structure):
                 ("pool", ctypes.c_int32), ("out_store", ctypes.c_int32),
                 ("res", ctypes.c_void_p), ("res_store", ctypes.c_int32), ("res_bits", ctypes.c_int32),
                 ("post_scale", ctypes.c_float), ("trick_c", ctypes.c_float), ("trick_s", ctypes.c_float),
-                ("fold", ctypes.c_void_p), ("domain_flag", ctypes.c_void_p)]
+                ("fold", ctypes.c_void_p), ("flags", ctypes.c_uint32), ("domain_flag", ctypes.c_void_p)]
 
 
 class FoldInfo(ctypes.Structure):
@@ -83,7 +83,6 @@ def load():
     lib.qnn_last_error.restype = ctypes.c_char_p
     lib.qnn_last_kernel.restype = ctypes.c_char_p
     lib.qnn_set_conv_impl.argtypes = [ci]
-    lib.qnn_set_option.argtypes = [ctypes.c_char_p, ci]
     lib.qnn_binary_tanh_f32.argtypes = [vp, vp, sz, vp]
     lib.qnn_quantized_tanh_f32.argtypes = [vp, vp, sz, ci, vp]
     lib.qnn_ternary_tanh_f32.argtypes = [vp, vp, sz, vp, vp]
@@ -138,11 +137,34 @@ def set_conv_impl(impl):
     _conv_impl = int(impl)
 
 
+EPI_NO_STRIP, EPI_NO_STRIP64, EPI_NO_HALO, EPI_NO_LDS16 = 1, 2, 4, 8      # qnn_epilogue_t.flags (qnn_abi.h)
+_default_flags = 0
+_default_first = None
+
+
 def set_option(key, value):
-    """Kernel-selection switch (qnn_set_option).  "strip" 0 / 1, "strip64" -1 / 0 / 1 and "halo" 0 / 1: results are bit-identical
-    under every setting.  "first_fixed" 0 / 1: the opt-in fixed-point first layer (csrc/qnn_first_fixed.hip) -- within 1e-5 of
-    the ideal convolution but NOT the oracle's float32 chain; off by default."""
-    check(load().qnn_set_option(key.encode(), int(value)), "qnn_set_option")
+    """TEST / TOOL HELPER of this binding -- the C library keeps no such state (round 4: qnn_set_option is gone from the
+    ABI).  Sets what calls made THROUGH THIS MODULE pass per call when the caller says nothing:
+      "strip" 0 / 1, "strip64" -1 / 0 / 1, "halo" 0 / 1, "lds16" 0 / 1   -> qnn_epilogue_t.flags (QNN_EPI_NO_*): kernel
+                  selection only, results bit-identical;
+      "first_fixed" / "first_image" 0 / 1   -> a plain float32 input store is declared QNN_STORE_F32_UNIT /
+                  QNN_STORE_F32_IMAGE (the typed stores the engines pass explicitly)."""
+    global _default_flags, _default_first
+    bits = {"strip": EPI_NO_STRIP, "strip64": EPI_NO_STRIP64, "halo": EPI_NO_HALO, "lds16": EPI_NO_LDS16}
+    if key in bits:
+        _default_flags = (_default_flags | bits[key]) if int(value) == 0 else (_default_flags & ~bits[key])
+    elif key in ("first_fixed", "first_image"):
+        store = STORE_F32_UNIT if key == "first_fixed" else STORE_F32_IMAGE
+        if int(value):
+            _default_first = store
+        elif _default_first == store:
+            _default_first = None
+    else:
+        raise QnnError("set_option: unknown key %r" % (key,))
+
+
+def _first_store(x_store):
+    return _default_first if (x_store == STORE_F32 and _default_first is not None) else x_store
 
 
 def conv_impl():
@@ -293,13 +315,14 @@ def out_hw(size, k, stride, same_pad):
 
 
 def make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res=None, res_store=STORE_F32,
-                  res_bits=0, post_scale=1.0, trick=None, fold=None, domain_flag=None):
+                  res_bits=0, post_scale=1.0, trick=None, fold=None, domain_flag=None, flags=None):
     """trick: None (the reference's lr-multiplier identity trick is the identity) or the (c, s) float32 pair of its
     OUTPUT side, `faithful_trick(klm, promotion)`.  fold: a Fold prepared for exactly this layer and epilogue."""
     tc, ts = (float(trick[0]), float(trick[1])) if trick is not None else (0.0, 0.0)
     return Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store,
                     ptr(res).value, res_store, res_bits, float(post_scale), tc, ts,
                     fold.handle.value if fold is not None else None,
+                    _default_flags if flags is None else int(flags),
                     ptr(domain_flag).value if domain_flag is not None else None)
 
 
@@ -391,7 +414,7 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
         y = out
     epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale, trick, fold,
                         domain_flag)
-    check(load().qnn_conv2d_forward(w.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(epi),
+    check(load().qnn_conv2d_forward(w.handle, ptr(x), _first_store(x_store), x_bits, N, H, W, ctypes.byref(epi),
                                     ptr(y), stream_ptr()), "qnn_conv2d_forward")
     return y, Ho, Wo
 
@@ -445,7 +468,7 @@ class BoundStep:
         lib = load()
         if kind == "conv":
             self._fn = lib.qnn_conv2d_forward
-            self._mid = (x_store, x_bits, N, H, W, ctypes.byref(self._epi))
+            self._mid = (_first_store(x_store), x_bits, N, H, W, ctypes.byref(self._epi))
         else:
             self._fn = lib.qnn_dense_forward
             self._mid = (x_store, x_bits, N, ctypes.byref(self._epi))

@@ -75,14 +75,10 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
 int qnn_conv_impl_pref();
 int qnn_head_prepare(qnn_weights* w, hipStream_t s);
 int qnn_try_launch_stem(const ConvGeom& g, const EpiArgs& e, const void* x, const float* wq, void* y, hipStream_t s);
-int qnn_option(int which);
-void qnn_set_call_first_mode(int mode);   // thread-local: domain declared for this call's float32 input (conv_forward)
-int qnn_call_first_mode();
 int qnn_try_launch_first_fixed(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                                hipStream_t s);
 int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, const qnn_weights* w, void* y,
                             hipStream_t s, bool f32in);
-enum { QNN_OPT_STRIP = 0, QNN_OPT_STRIP64 = 1, QNN_OPT_FIRST_FIXED = 2, QNN_OPT_FIRST_IMAGE = 3, QNN_OPT_HALO = 4, QNN_OPT_COUNT = 5 };
 
 // ---- division by a launch-constant via multiply-high (dividends < 2^31) ----------
 struct FastDiv {
@@ -134,6 +130,8 @@ struct EpiArgs {
     float trick_c, trick_s;    // output-side identity trick of the reference ("faithful" mode); trick_s == 0: off
     const float* fold_a;       // qnn_fold_t of this layer + epilogue (qnn_fold.h): per-channel slope, or nullptr = evaluate
     const int32_t* fold_b;     // the float32 chain; per-channel accumulator offset in units of acc / 256
+    uint32_t flags;            // QNN_EPI_* kernel-selection bits of this call (qnn_epilogue_t.flags)
+    int first_mode;            // domain declared for this call's float32 input: 0 none, 1 image bytes / 255, 2 [0, 1]
     uint32_t* dom_flag;        // the caller's domain-flag word for this call (qnn_epilogue_t.domain_flag) or nullptr = the handle's
     const float* fold_c;       // "bits" form of the fold (fold_b carries 0x4B400000, u = fma(as_float(acc), a, c)), or nullptr
 };

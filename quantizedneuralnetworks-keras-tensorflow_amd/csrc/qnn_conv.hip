@@ -1140,6 +1140,8 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
     e->fold_b = nullptr;
     e->fold_c = nullptr;
     e->dom_flag = epi->domain_flag;
+    e->flags = epi->flags;
+    e->first_mode = 0;
     if (epi->fold) {
         // the fold must have been prepared for exactly this layer and epilogue; a handle whose sweep found a differing
         // point on some channel (folded < cout) is accepted and ignored: the kernels evaluate the float32 chain
@@ -1201,16 +1203,13 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
                  int W, const qnn_epilogue_t* epi, void* y, void* stream, bool dense) {
     QNN_REQUIRE(w && x && y && epi, QNN_EINVAL, "conv_forward: null pointer");
     QNN_REQUIRE(N >= 0 && H > 0 && W > 0, QNN_EINVAL, "conv_forward: N=%d H=%d W=%d", N, H, W);
-    // float32 input with a declared domain (typed entry of this call, or the process-wide default): kept for the
-    // first-layer dispatch of this call on this thread
+    // float32 input with a declared domain (the typed entry of this call): handed to the first-layer dispatch in the
+    // epilogue arguments
     int first_mode = 0;
     if (x_store == QNN_STORE_F32_IMAGE || x_store == QNN_STORE_F32_UNIT) {
         first_mode = x_store == QNN_STORE_F32_IMAGE ? 1 : 2;
         x_store = QNN_STORE_F32;
-    } else if (x_store == QNN_STORE_F32) {
-        first_mode = qnn_option(QNN_OPT_FIRST_IMAGE) ? 1 : qnn_option(QNN_OPT_FIRST_FIXED) ? 2 : 0;
     }
-    qnn_set_call_first_mode(first_mode);
     int xshift = 0;
     if (x_store == QNN_STORE_F32) {
         // any float32 values; uses the float32 copy of the quantized kernel
@@ -1254,6 +1253,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     EpiArgs e;
     int rc = check_epilogue(w, epi, xshift, &e);
     if (rc != QNN_OK) return rc;
+    e.first_mode = first_mode;
     if (x_store == QNN_STORE_F32) e.scale = 1.0f;   // d_wq holds real values already
     if (x_store == QNN_STORE_U8) e.scale = 255.0f * (float)(1 << w->wshift);   // the divisor D of the affine map
     // a restricted-domain kernel (first_fixed) saw a value outside its domain in an earlier launch of this layer, and

@@ -782,12 +782,12 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
         const int pw = e.out_store == QNN_STORE_F32 ? 1 : qnn_per_word(e.out_store);
         if (g.cout % pw != 0) return 1;
         // opt-in: float32 inputs that are image bytes / 255 on the uint8 entry's kernel (qnn_first_u8.hip, F32IN)
-        if (qnn_call_first_mode() == 1 && qnn_try_launch_first_u8(g, e, x, w, y, s, true) == 0) {
+        if (e.first_mode == 1 && qnn_try_launch_first_u8(g, e, x, w, y, s, true) == 0) {
             snprintf(name, name_len, "mfma_i8_first_img255");
             return 0;
         }
         // opt-in fixed-point variant (qnn_first_fixed.hip): NOT the oracle's float32 chain, see its header
-        if (qnn_call_first_mode() == 2 && qnn_try_launch_first_fixed(g, e, x, w, y, s) == 0) {
+        if (e.first_mode == 2 && qnn_try_launch_first_fixed(g, e, x, w, y, s) == 0) {
             snprintf(name, name_len, "mfma_i8x3_first_fixed");
             return 0;
         }
@@ -822,9 +822,8 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
         // Cin 64 (auto): every un-pooled layer.  Measured, 64 x 56^2 / 4096 x 16^2 pixels, round 3 (one 32-bit store and one
         // shortcut load per row): with the merge 13.9 us here against 36.4 us on the LDS-weight kernel, without it
         // 13.1 / 43.5 against 14.0 / 46.5 (round 2, two 16-bit accesses per row: 16.3 / 54.6 against 14.1 / 47.3).
-        const int s64 = qnn_option(QNN_OPT_STRIP64);
-        const bool want = g.cin == 64 ? s64 != 0 : true;
-        if (shape && want && qnn_option(QNN_OPT_STRIP)) {
+        const bool want = g.cin == 64 ? !(e.flags & QNN_EPI_NO_STRIP64) : true;
+        if (shape && want && !(e.flags & QNN_EPI_NO_STRIP)) {
             MfmaGeom ms;
             ms.g = g; ms.kc = 1; ms.steps = 0; ms.x_pix_bytes = g.cin / 2;
             ms.total_q = (long)g.N * g.H * g.W;
@@ -836,7 +835,7 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                 // 16 -> 16 channels with a usable fold and an even width: the LDS-staged form (qnn_mfma_strip16.hip: a sixth
                 // of the load and a quarter of the store instructions)
                 static const bool lds16_off = QNN_ENV_STR("QNN_STRIP16_LDS_OFF") != nullptr;   // A/B switch (experiment builds only)
-                if (g.cin == 16 && !lds16_off && qnn_launch_strip16_lds(ms, es, x, w->d_mfma, y, s) == 0) {
+                if (g.cin == 16 && !lds16_off && !(e.flags & QNN_EPI_NO_LDS16) && qnn_launch_strip16_lds(ms, es, x, w->d_mfma, y, s) == 0) {
                     snprintf(name, name_len, "strip_i4_c16_lds");
                     return 0;
                 }
@@ -906,7 +905,7 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     if (e.res && !(areg && g.pool == 1)) return 1;          // the other MFMA kernels have no residual epilogue
     // pooled int4 layers whose pooled map tiles into 8 x 2 / 4 x 4 rectangles: receptive field staged once through LDS
     // (k_conv_mfma_halo, qnn_mfma_areg.hip; qnn_set_option("halo", 0) keeps them on the per-tap kernel below)
-    if (areg && x_store == QNN_STORE_I4 && qnn_option(QNN_OPT_HALO) &&
+    if (areg && x_store == QNN_STORE_I4 && !(e.flags & QNN_EPI_NO_HALO) &&
         qnn_launch_halo(mg, e2, x, w->d_mfma, y, s) == 0) {
         snprintf(name, name_len, "mfma_i4_halo64x64");
         return 0;

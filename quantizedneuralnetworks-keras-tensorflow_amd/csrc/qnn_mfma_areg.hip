@@ -1208,7 +1208,7 @@ int qnn_launch_areg_head(const MfmaGeom& mg, const EpiArgs& e, const void* x, co
     HeadArgs hd;
     hd.tab = wd->d_head; hd.bias = ed.bias; hd.bn_inv = ed.bn_inv; hd.bn_shift = ed.bn_shift;
     hd.scale = ed.scale; hd.units = wd->cout; hd.y = y;
-    if (qnn_option(QNN_OPT_HALO) && halo_width(mg, e) == 4 && g.Wp == 4) {   // tile == image
+    if (!(e.flags & QNN_EPI_NO_HALO) && halo_width(mg, e) == 4 && g.Wp == 4) {   // tile == image
         if (halo_waves(mg, 4) == 8) launch_halo_one<4, 8, true>(mg, e, x, w, nullptr, hd, s);
         else launch_halo_one<4, 4, true>(mg, e, x, w, nullptr, hd, s);
         *kname = "mfma_i4_halo64x64+dense";

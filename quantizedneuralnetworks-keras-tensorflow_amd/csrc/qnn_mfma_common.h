@@ -258,4 +258,3 @@ int qnn_launch_small(int cin, const MfmaGeom& mg, const EpiArgs& e, const void* 
 int qnn_launch_strip(int cin, const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w,
                      void* y, hipStream_t s);
 int qnn_launch_strip16_lds(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, hipStream_t s);
-int qnn_option(int which);   // qnn_api.hip: QNN_OPT_* switches set through qnn_set_option()

@@ -542,6 +542,77 @@ def gen_first(out, state):
     out["index_json"] = np.frombuffer(json.dumps({"first": cases}).encode(), dtype=np.uint8)
 
 
+def gen_bench_first(out, state, images=4096, chunk=256):
+    """The headline benchmark's first conv group -- models/vgg.py:15-17 + the MaxPooling2D of line 23: QuantizedConv2D(nb=4)
+    .call(), BatchNormalization, quantized_tanh(nb=4), 2x2 max pool -- RUN BY THE REFERENCE on the 4096 benchmark images
+    with the benchmark's own weights (nets.build_spec(baseline_config(2), SEED_BASE + 2), bench.py), under both scalar
+    promotions.  67 M activation codes per variant are far too many to commit; committed are
+      * the SHA-256 of each pooled code tensor (int8, shape (4096, 16, 16, 64)),
+      * the sparse set of positions where the reference (either promotion), the oracle's exact float32 chain and the
+        oracle's QNN_STORE_U8 specification do not all agree, with the four code values at each of them,
+    so a test can rebuild the reference's tensor from ANY of the three others and check it against the digest.  This is
+    where the byte entries' rare code flips (about one first-layer code in a million) are pinned against the reference."""
+    import hashlib
+    import importlib
+    repo = os.path.dirname(os.path.dirname(HERE))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    pkg = importlib.import_module("quantizedneuralnetworks-keras-tensorflow_amd")
+    nets = pkg.nets
+    from oracle import qnn_oracle as O
+    from layers.quantized_layers import QuantizedConv2D
+    from layers.quantized_ops import quantized_tanh
+    cf = nets.baseline_config(2)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 2)
+    conv, bn, act, pool = spec[0], spec[1], spec[2], spec[3]
+    assert conv["op"] == "conv" and bn["op"] == "bn" and act["fn"] == "quantized_tanh" and act["nb"] == 4 and pool["op"] == "maxpool"
+    xu8 = nets.synthetic_images_u8(cf, images, nets.SEED_BASE + 2)            # rank 0's batch in bench.py
+    kern, bias = conv["kernel"], conv.get("bias")
+    state["provider"] = lambda layer, name, shp: kern if name == "kernel" else bias
+    layer = QuantizedConv2D(filters=kern.shape[3], kernel_size=(3, 3), strides=(1, 1), padding="same",
+                            use_bias=bias is not None, H=1., nb=int(conv["nb"]))
+    layer.build((None, cf.dim, cf.dim, cf.channels))
+    klm = layer.kernel_lr_multiplier
+    assert isinstance(klm, np.float32)
+
+    def pooled_codes(v):                      # activation values k/8 -> int8 codes, 2x2 max pool
+        c = np.rint(np.asarray(v, dtype=np.float64) * 8.0).astype(np.int8)
+        n, h, w, ch = c.shape
+        return c.reshape(n, h // 2, 2, w // 2, 2, ch).max(axis=(2, 4))
+
+    parts = {"legacy": [], "nep50": [], "exact": [], "u8": []}
+    for i in range(0, images, chunk):
+        xb = xu8[i:i + chunk]
+        x = (xb.astype(F32) / 255).astype(F32)                                # utils/load_data.py:40
+        for prom in ("nep50", "legacy"):
+            layer.kernel_lr_multiplier = klm if prom == "nep50" else np.float64(klm)
+            y = layer.call(Tensor(x))
+            y = _batch_normalization(y, bn["mean"], bn["var"], bn["beta"], bn["gamma"], epsilon=bn["eps"])
+            parts[prom].append(pooled_codes(_t(quantized_tanh(y, nb=4)).a))
+        parts["exact"].append(pooled_codes(O.run_spec([conv, bn, act], x, float_conv="device")))
+        parts["u8"].append(pooled_codes(O.u8_conv_group(xb, conv, bn, act)))
+    codes = {k: np.concatenate(v) for k, v in parts.items()}
+    differ = np.zeros(codes["legacy"].shape, dtype=bool)
+    for k in ("nep50", "exact", "u8"):
+        differ |= codes[k] != codes["legacy"]
+    pos = np.flatnonzero(differ).astype(np.int64)
+    out["pos"] = pos
+    summary = {"images": images, "shape": list(codes["legacy"].shape), "seed": int(nets.SEED_BASE + 2), "klm": float(klm),
+               "codes": int(codes["legacy"].size), "positions": int(pos.size)}
+    for k, c in codes.items():
+        out["at_" + k] = c.reshape(-1)[pos]
+        summary["sha256_" + k] = hashlib.sha256(np.ascontiguousarray(c).tobytes()).hexdigest()
+    for ref in ("legacy", "nep50"):
+        for k in ("exact", "u8"):
+            d = codes[k].astype(np.int16) - codes[ref].astype(np.int16)
+            summary["flips_%s_vs_%s" % (k, ref)] = int(np.count_nonzero(d))
+            summary["maxabs_%s_vs_%s" % (k, ref)] = int(np.abs(d).max())
+    summary["flips_nep50_vs_legacy"] = int(np.count_nonzero(codes["nep50"] != codes["legacy"]))
+    summary["flips_u8_vs_exact"] = int(np.count_nonzero(codes["u8"] != codes["exact"]))
+    out["index_json"] = np.frombuffer(json.dumps({"bench_first": summary}).encode(), dtype=np.uint8)
+    return summary
+
+
 class Cf:
     def __init__(self, **kw):
         self.kernel_initializer, self.kernel_regularizer = "he_normal", 1e-4
@@ -685,7 +756,10 @@ def main():
     first = {}
     gen_first(first, state)
     np.savez_compressed(os.path.join(HERE, "ref_first.npz"), **first)
-    for f in ("ref_ops.npz", "ref_layers.npz", "ref_models.npz", "ref_first.npz"):
+    bench_first = {}
+    print(json.dumps(gen_bench_first(bench_first, state), indent=1))
+    np.savez_compressed(os.path.join(HERE, "ref_bench_first.npz"), **bench_first)
+    for f in ("ref_ops.npz", "ref_layers.npz", "ref_models.npz", "ref_first.npz", "ref_bench_first.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
     print(json.dumps({k: (len(v) if isinstance(v, list) else v) for k, v in index.items()}, indent=1))
 

@@ -29,7 +29,6 @@ CHILD = textwrap.dedent(r'''
     lib.qnn_packed_bytes.argtypes = [ci, sz, ci]
     lib.qnn_conv2d_workspace_bytes.restype = sz
     lib.qnn_conv2d_workspace_bytes.argtypes = [vp, ci, ci, ci]
-    lib.qnn_set_option.argtypes = [ctypes.c_char_p, ci]
     lib.qnn_binary_tanh_f32.argtypes = [vp, vp, sz, vp]
     lib.qnn_quantized_tanh_f32.argtypes = [vp, vp, sz, ci, vp]
     lib.qnn_ternary_tanh_f32.argtypes = [vp, vp, sz, vp, vp]
@@ -60,10 +59,7 @@ CHILD = textwrap.dedent(r'''
     expect(lib.qnn_set_conv_impl(5), EINVAL, "set_conv_impl(5)")
     expect(lib.qnn_set_conv_impl(-1), EINVAL, "set_conv_impl(-1)")
     expect(lib.qnn_set_conv_impl(0), 0, "set_conv_impl(0)")
-    expect(lib.qnn_set_option(b"bogus", 1), EINVAL, "set_option(bogus)")
-    expect(lib.qnn_set_option(None, 1), EINVAL, "set_option(NULL)")
-    expect(lib.qnn_set_option(b"strip", 0), 0, "set_option(strip)")
-    expect(lib.qnn_set_option(b"strip64", -1), 0, "set_option(strip64)")
+    assert not hasattr(lib, "qnn_set_option")          # round 4: no process-wide kernel switches in the library
     # elementwise clips
     expect(lib.qnn_binary_tanh_f32(None, FAKE, 10, None), EINVAL, "binary_tanh null x")
     expect(lib.qnn_binary_tanh_f32(FAKE, None, 10, None), EINVAL, "binary_tanh null y")

@@ -529,7 +529,54 @@ def test_full_batch_4096_on_the_byte_entries(idx):
                                                             (y8.argmax(1) == ye.argmax(1)).mean()))
     # measured: config 2 (1-bit) 0 rows, config 3 (4-bit) 51 rows = roughly one first-layer code in 1.3 million whose
     # pre-activation sits closer to a rounding threshold than the float32 chain's own error; one argmax of 4096 moves
-    assert rows <= 100 and (y8.argmax(1) == ye.argmax(1)).mean() >= 0.999
+    # (round 4: asserted at the measured values -- the inputs are seeded -- and the size of the difference bounded; where
+    # these flips sit relative to the REFERENCE is pinned by test_benchmark_first_layer_codes_against_the_reference_run)
+    assert rows == {1: 0, 2: 51}[idx] and float(np.abs(y8 - ye).max()) <= {1: 0.0, 2: 0.09}[idx]
+    assert (y8.argmax(1) == ye.argmax(1)).mean() >= 0.9997
     # the product call: same bits from predict() on numpy bytes
     got = nets.Model(cf, spec, first_layer="exact").predict(xu8, batch_size=1024)
     np.testing.assert_array_equal(got, y8)
+
+
+def test_benchmark_first_layer_codes_against_the_reference_run():
+    """Where the byte entries' rare code flips actually occur: the first conv group of the headline benchmark (models/vgg.py:
+    15-17, 23) on the 4096 benchmark images.  tests/golden/ref_bench_first.npz holds what the REFERENCE computes there
+    (QuantizedConv2D.call + BatchNormalization + quantized_tanh + max pool, both scalar promotions): the SHA-256 of each
+    67 M-code tensor plus every position where reference, exact oracle and uint8 specification do not all agree.
+    For every entry of the product (exact / image / auto / uint8):
+      * at the listed positions the kernel equals ITS OWN oracle (exact chain or uint8 specification), value for value;
+      * with the reference's values written over those positions the tensor hashes to the reference's digest -- so on all
+        other 67 M positions the kernel's code IS the reference's;
+      * hence its flips against the reference are exactly the fixture's counts (asserted, not bounded) and never more
+        than one code step."""
+    import hashlib
+    import json
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_bench_first.npz"))
+    idx = json.loads(bytes(z["index_json"]).decode())["bench_first"]
+    cf = nets.baseline_config(2)
+    spec = nets.build_spec(cf, nets.SEED_BASE + 2)
+    assert idx["seed"] == nets.SEED_BASE + 2 and idx["images"] == 4096
+    xu8 = nets.synthetic_images_u8(cf, idx["images"], idx["seed"])
+    pos = z["pos"]
+    print("[bench first layer vs reference] %d codes, %d listed positions; flips vs legacy / nep50: exact %d / %d, uint8 %d / %d"
+          % (idx["codes"], idx["positions"], idx["flips_exact_vs_legacy"], idx["flips_exact_vs_nep50"],
+             idx["flips_u8_vs_legacy"], idx["flips_u8_vs_nep50"]))
+    for entry, own in (("exact", "exact"), ("image", "u8"), ("auto", "u8"), ("u8", "u8")):
+        m = engine.FusedModel(spec, first_layer="exact" if entry == "u8" else entry)
+        x = dev(xu8) if entry == "u8" else dev((xu8.astype(F32) / F32(255)).astype(F32))
+        y, hp, wp = m.run_step(0, x, idx["images"], cf.dim, cf.dim)
+        st = m.steps[0]
+        vals = _abi.unpack(y, idx["images"] * hp * wp, st["w"].shape[3], st["out_store"], 4)
+        codes = torch.round(vals * 8).to(torch.int8)
+        del vals, y
+        flat = host(codes).reshape(-1)
+        assert list(codes.shape) == [idx["images"] * hp * wp, idx["shape"][3]] and flat.size == idx["codes"]
+        np.testing.assert_array_equal(flat[pos], z["at_" + own], err_msg=entry)
+        for ref in ("legacy", "nep50"):
+            patched = flat.copy()
+            patched[pos] = z["at_" + ref]
+            assert hashlib.sha256(patched.tobytes()).hexdigest() == idx["sha256_" + ref], (entry, ref)
+            d = z["at_" + own].astype(np.int16) - z["at_" + ref].astype(np.int16)
+            assert int(np.count_nonzero(d)) == idx["flips_%s_vs_%s" % (own, ref)], (entry, ref)
+            assert int(np.abs(d).max(initial=0)) == idx["maxabs_%s_vs_%s" % (own, ref)] <= 1, (entry, ref)
+        m.check_domain()
