@@ -696,17 +696,6 @@ def main_rank(args):
         cache_resident = {"value": global_batch * args.steps / float(np.median(rr)), "unit": "images/s",
                           "note": "every lane replays ONE 50 MB input batch, which stays in the 256 MB Infinity Cache"}
 
-    gather_every_1 = None
-    if pipelined and G > 1:
-        every1[0] = True
-        for _ in range(args.warmup):
-            run_step()
-        drain()
-        r1 = [timed_region() for _ in range(max(3, args.repeats))]
-        every1[0] = False
-        gather_every_1 = {"value": global_batch * args.steps / float(np.median(r1)), "unit": "images/s",
-                          "note": "one RCCL all-gather of the logits per batch instead of one per %d batches of a lane" % G}
-
     ring_check = None
     if pipelined and rank == 0:
         # a gathered block must hold this rank's ring at its own offset, bit for bit and finite; and a ring slot the
@@ -722,6 +711,17 @@ def main_rank(args):
         eager = model(ln["xs"][j0 % len(ln["xs"])] if "xs" in ln else ln["x"])
         torch.testing.assert_close(ln["gathered"][0][rank * nloc:rank * nloc + ln["B"]], eager, rtol=0, atol=0)
         ring_check = "gathered == ring (finite, bit for bit); slot 0 == eager forward of its input batch"
+
+    gather_every_1 = None
+    if pipelined and G > 1:
+        every1[0] = True
+        for _ in range(args.warmup):
+            run_step()
+        drain()
+        r1 = [timed_region() for _ in range(max(3, args.repeats))]
+        every1[0] = False
+        gather_every_1 = {"value": global_batch * args.steps / float(np.median(r1)), "unit": "images/s",
+                          "note": "one RCCL all-gather of the logits per batch instead of one per %d batches of a lane" % G}
 
     # which physical devices took part: every rank reports its own (uuid, PCI bus id, name); gathered on rank 0
     props = torch.cuda.get_device_properties(torch.cuda.current_device())

@@ -1111,7 +1111,7 @@ int try_launch_ps(const ConvGeom& g, const EpiArgs& e, int x_store, const void* 
     return 1;
 }
 
-int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, EpiArgs* e) {
+int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, EpiArgs* e, int x_store = -1, int first_mode = 0) {
     e->bias = w->d_bias;
     e->bn_inv = epi->bn_inv;
     e->bn_shift = epi->bn_shift;
@@ -1147,14 +1147,17 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
         // point on some channel (folded < cout) is accepted and ignored: the kernels evaluate the float32 chain
         const qnn_fold* f = epi->fold;
         const bool has_res = epi->res != nullptr;
+        // (a fold of the image entry, mode 3, serves the QNN_STORE_U8 and the QNN_STORE_F32_IMAGE calls of its layer)
+        const bool xs_ok = f->mode == 3 ? (x_store == QNN_STORE_U8 || (x_store == QNN_STORE_F32 && first_mode == 1))
+                                        : (f->x_bits == xshift + 1 && x_store != QNN_STORE_U8 && x_store != QNN_STORE_F32);
         QNN_REQUIRE(f->w == w && f->bn_inv == epi->bn_inv && f->bn_shift == epi->bn_shift && f->fn == epi->fn &&
-                        f->act_bits == epi->act_bits && f->out_store == epi->out_store && f->x_bits == xshift + 1 &&
+                        f->act_bits == epi->act_bits && f->out_store == epi->out_store && xs_ok &&
                         (f->has_res != 0) == has_res &&
                         (!has_res || (f->res_store == epi->res_store && f->res_bits == epi->res_bits &&
                                       f->post_scale == epi->post_scale)) &&
                         epi->trick_s == 0.0f,
                     QNN_EINVAL, "epilogue: the fold handle was prepared for another layer / epilogue (qnn_fold_prepare)");
-        if (f->folded == f->cout) { e->fold_a = f->d_a; e->fold_b = f->d_b; e->fold_c = f->mode == 2 ? f->d_c : nullptr; }
+        if (f->folded == f->cout) { e->fold_a = f->d_a; e->fold_b = f->d_b; e->fold_c = f->mode >= 2 ? f->d_c : nullptr; }
     }
     QNN_REQUIRE(epi->trick_s == 0.0f || (epi->trick_s > 0.0f && epi->trick_s < 1.0e6f), QNN_EINVAL,
                 "epilogue: trick_s=%g (the layer's kernel_lr_multiplier, or 0)", (double)epi->trick_s);
@@ -1251,7 +1254,7 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     g.fd_wp = qnn_fastdiv((uint32_t)g.Wp);
     g.fd_hp = qnn_fastdiv((uint32_t)g.Hp);
     EpiArgs e;
-    int rc = check_epilogue(w, epi, xshift, &e);
+    int rc = check_epilogue(w, epi, xshift, &e, x_store, first_mode);
     if (rc != QNN_OK) return rc;
     e.first_mode = first_mode;
     if (x_store == QNN_STORE_F32) e.scale = 1.0f;   // d_wq holds real values already

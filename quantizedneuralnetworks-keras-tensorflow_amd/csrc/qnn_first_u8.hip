@@ -19,6 +19,7 @@
 // lane holds the four positions of ONE window for one filter: pooling is an in-lane max on the integers (filters of
 // channels with negative BN scale are negated, A[c] with them).
 #include "qnn_mfma_common.h"
+#include "qnn_fold.h"
 
 namespace {
 
@@ -46,7 +47,10 @@ __device__ __forceinline__ uint32_t image_byte(float x, bool& bad) {
 
 // (QNN_STORE_I4, 2, BIN): the fused pipeline, quantized_tanh / binary_tanh codes;  (QNN_STORE_F32, 1, false): the layer
 // behind the float32 surface (any fn)
-template <int OUT, int POOL, bool BIN, bool F32IN>
+// FOLD (round 4): the epilogue of the pooled int4 form as qnn_fold.h's mode 3 -- u = fma(float(S), A2, C2), one
+// v_cvt_pknorm_i16_f32 per pair, two v_perm_b32 + shift + v_bfi_b32 per eight values -- with A2 / C2 from a fold handle that
+// qnn_fold_prepare accepted only after it reproduced  clip(rint(fma(float(S), A, B)))  on every S the filter can produce.
+template <int OUT, int POOL, bool BIN, bool F32IN, bool FOLD = false>
 __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e, const void* __restrict__ x,
                                                            const float* __restrict__ wq, void* __restrict__ y,
                                                            int ntasks, int spr, FastDiv fd_spr, int nch, FastDiv fd_nch,
@@ -95,7 +99,8 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
         // the affine map behind S (qnn_abi.h): float64 from the float32 constants, one rounding each
         const double m = e.fn == QNN_FN_QUANTIZED_TANH ? (double)e.act_m : 1.0;
         float A = (float)((double)inv * m / (double)D);
-        const float B = (float)(((double)bias * (double)inv + (double)shift) * m);
+        float B = (float)(((double)bias * (double)inv + (double)shift) * m);
+        if constexpr (FOLD) { A = e.fold_a[c]; B = e.fold_c[c]; }
         if (flip) A = -A;
         tab[(wave * 64 + lane) * 2] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
         tab[(wave * 64 + lane) * 2 + 1] = make_uint4(__float_as_uint(A), __float_as_uint(B), 0u, 0u);
@@ -225,7 +230,17 @@ __global__ __launch_bounds__(256, 4) void k_conv_first_u8(ConvGeom g, EpiArgs e,
                     acc[(gq + 1) & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[(gq + 1) >> 2], bw[(gq + 1) & 3], z, 0, 0, 0);
                 consume(gq, acc[gq & 1]);
             }
-            if constexpr (OUT == QNN_STORE_I4) {
+            if constexpr (OUT == QNN_STORE_I4 && FOLD) {
+                static_assert(!FOLD || (!BIN && POOL == 2), "the fold covers the pooled quantized_tanh form");
+                uint32_t tp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)             // pairs (value j, value j + 4): same filter block, tiles 0 and 1
+                    tp[j] = qnn_fold_pair_fma(T[j], T[j + 4], fa[j], fa[j], fb[j], fb[j]);
+                const uint32_t uo = __builtin_amdgcn_perm(tp[3], tp[1], 0x07030501u);
+                const uint32_t ue = __builtin_amdgcn_perm(tp[2], tp[0], 0x07030501u);
+                const uint32_t P = (uo & 0xF0F0F0F0u) | ((ue >> 4) & 0x0F0F0F0Fu);      // nibble j = code of value j
+                __builtin_amdgcn_raw_buffer_store_b32(transpose_nib8(P, ke), yr, ylane, rp * yrow, 0);
+            } else if constexpr (OUT == QNN_STORE_I4) {
                 // lane (filter r, window kq): value j = 4*t + nt -> after the transpose lane (r & 7) holds the word of
                 // value j = r & 7: pooled pixel (xs/2 + kq + 4*(j >> 2)), channels (j & 3)*16 + (r & 8) .. +7
                 int cb[8];
@@ -591,6 +606,16 @@ int qnn_try_launch_first_u8(const ConvGeom& g, const EpiArgs& e, const void* x, 
     } while (0)
     if (!fused) U8_LAUNCH(QNN_STORE_F32, 1, false);
     else if (e.fn == QNN_FN_BINARY_TANH) U8_LAUNCH(QNN_STORE_I4, 2, true);
+    else if (e.fold_a && e.fold_c && e.act_m == 8.0f) {       // folded epilogue (mode 3 handle of this layer, qnn_fold.h)
+        if (f32in)
+            hipLaunchKernelGGL((k_conv_first_u8<QNN_STORE_I4, 2, false, true, true>), grid, block, lds, s, g, e, x, w->d_wq, y,
+                               (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),
+                               best_rc, (uint32_t)img_x, wscale, D, (e.dom_flag ? e.dom_flag : w->d_flag));
+        else
+            hipLaunchKernelGGL((k_conv_first_u8<QNN_STORE_I4, 2, false, false, true>), grid, block, lds, s, g, e, x, w->d_wq, y,
+                               (int)ntasks_l, spr, qnn_fastdiv((uint32_t)spr), best_nch, qnn_fastdiv((uint32_t)best_nch),
+                               best_rc, (uint32_t)img_x, wscale, D, (e.dom_flag ? e.dom_flag : w->d_flag));
+    }
     else U8_LAUNCH(QNN_STORE_I4, 2, false);
 #undef U8_LAUNCH
     return 0;

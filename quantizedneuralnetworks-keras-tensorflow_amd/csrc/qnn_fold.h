@@ -37,6 +37,14 @@ __device__ __forceinline__ uint32_t qnn_fold_pair_bits(int acc0, int acc1, float
     const float u0 = __fmaf_rn(__int_as_float(acc0), a0, c0), u1 = __fmaf_rn(__int_as_float(acc1), a1, c1);
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(u0, u1));
 }
+// Third form (mode 3): the typed image entry (QNN_STORE_U8 / QNN_STORE_F32_IMAGE first layers), whose accumulator is the
+// exact integer S = sum byte * code in units of ONE (no widening, so no sub-step offset to play with): the folded form
+// keeps the conversion and takes its offset in the FMA,  u = fma(float(S), A, C),  and only the rounding add, the
+// integer median and the shift-adds of the packing go (v_cvt_pknorm_i16_f32 + v_perm_b32 / v_bfi_b32 instead).
+__device__ __forceinline__ uint32_t qnn_fold_pair_fma(int s0, int s1, float a0, float a1, float c0, float c1) {
+    const float u0 = __fmaf_rn((float)s0, a0, c0), u1 = __fmaf_rn((float)s1, a1, c1);
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(u0, u1));
+}
 template <int MODE>
 __device__ __forceinline__ uint32_t qnn_fold_pair_m(int acc0, int acc1, float a0, float a1, float c0, float c1) {
     if constexpr (MODE == 2) return qnn_fold_pair_bits(acc0, acc1, a0, a1, c0, c1);
@@ -52,7 +60,8 @@ __device__ __forceinline__ int qnn_fold_code_lo(uint32_t t) { return (int)(short
 __device__ __forceinline__ int qnn_fold_code_hi(uint32_t t) { return (int)t >> 28; }
 // one value: accw = accumulator + stored offset; mode 1 (conversion + multiply) or 2 (bits); sc ignored without a shortcut
 __device__ __forceinline__ int qnn_fold_code(int accw, float a, float c, int mode, bool res, int sc) {
-    uint32_t t = mode == 2 ? qnn_fold_pair_bits(accw, accw, a, a, c, c) : qnn_fold_pair(accw, accw, a, a);
+    uint32_t t = mode == 2 ? qnn_fold_pair_bits(accw, accw, a, a, c, c)
+                 : mode == 3 ? qnn_fold_pair_fma(accw, accw, a, a, c, c) : qnn_fold_pair(accw, accw, a, a);
     if (res) t = qnn_fold_merge(t, (uint32_t)((sc + 8) << 10) * 0x00010001u);
     return qnn_fold_code_lo(t);
 }
@@ -68,7 +77,8 @@ struct qnn_fold {
     int has_res, res_store, res_bits;
     float post_scale;
     int cout;
-    int mode;                      // 1: u = float(accw + beta) * A;  2 ("bits"): u = fma(as_float(accw + beta'), A, C)
+    int mode;                      // 1: u = float(accw + beta) * A;  2 ("bits"): u = fma(as_float(accw + beta'), A, C);
+                                   // 3 (image entry, x_store = QNN_STORE_U8): u = fma(float(S), A, C), no offset
     float* d_a;                    // [cout] slope
     int32_t* d_b;                  // [cout] offset, units of acc / 256 (mode 2: + 0x4B400000)
     float* d_c;                    // [cout] mode 2: C = float(-12582912 * A); mode 1: zeros

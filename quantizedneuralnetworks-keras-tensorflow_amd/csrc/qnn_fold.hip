@@ -185,6 +185,59 @@ __global__ __launch_bounds__(kThreads) void k_fold_prepare(FoldProblem p) {
     }
 }
 
+// ---- mode 3: the image entry.  chain = the entry's own specification (qnn_abi.h, qnn_conv2d_forward):
+// code = clip(rint(fma(float(S), A, B)), -8, 7) with A, B from qnn_u8_affine; domain S in 255 * [sum of the negative
+// weight codes, sum of the positive ones] ----
+struct FoldProblemU8 {
+    EpiArgs e;                       // e.scale = 255 * 2^wshift (the divisor D), bias / BN pointers, act_m, fn
+    const float* wq;                 // quantized weights [cout][K] as float32 values
+    int K;
+    float wscale;                    // 2^wshift: value -> integer code
+    float* A;
+    float* C;
+    int32_t* status;
+    int32_t* dom;
+    unsigned long long* points;
+};
+
+__global__ __launch_bounds__(kThreads) void k_fold_prepare_u8(FoldProblemU8 p) {
+    __shared__ long long sh[kThreads];
+    const int c = blockIdx.x, t = threadIdx.x;
+    long long lo = 0, hi = 0;
+    for (int k = t; k < p.K; k += kThreads) {
+        const int code = (int)rintf(__fmul_rn(p.wq[(size_t)c * p.K + k], p.wscale));
+        lo += code < 0 ? 255 * code : 0;
+        hi += code > 0 ? 255 * code : 0;
+    }
+    lo = block_sum(lo, sh);
+    hi = block_sum(hi, sh);
+    if (t == 0) { p.dom[2 * c] = (int)lo; p.dom[2 * c + 1] = (int)hi; p.status[c] = 0; p.A[c] = 0.0f; p.C[c] = 0.0f; p.points[c] = 0; }
+    const U8Affine af = qnn_u8_affine(p.e, c);
+    if (!(af.A == af.A) || !(af.B == af.B) || af.A == 0.0f) return;                    // uniform
+    const double k12 = 4096.0 / 32767.0;
+    const float a_nom = (float)((double)af.A * k12);
+    // snorm16 rounds to nearest and the code is the floor of the Q12 value: the -1/8192 centres the thresholds on k - 1/2
+    const float c_nom = (float)(((double)af.B + 0.5 - 1.0 / 8192.0) * k12);
+    const long long npts = hi - lo + 1;
+    for (int cand = 0; cand < 5 * 33; ++cand) {
+        const int ia = cand / 33, ic = cand % 33;
+        const int da = ia == 0 ? 0 : ((ia & 1) ? (ia + 1) / 2 : -(ia / 2));
+        const int dc = ic == 0 ? 0 : ((ic & 1) ? (ic + 1) / 2 : -(ic / 2));
+        const float A = __int_as_float(__float_as_int(a_nom) + da), C = __int_as_float(__float_as_int(c_nom) + dc);
+        long long bad = 0;
+        for (long long i = t; i < npts; i += kThreads) {
+            const int S = (int)(lo + i);
+            const int want = (int)qnn_u8_value(__fmaf_rn((float)S, af.A, af.B), p.e);
+            bad += want != qnn_fold_code(S, A, C, 3, false, 0);
+        }
+        bad = block_sum(bad, sh);
+        if (bad == 0) {
+            if (t == 0) { p.A[c] = A; p.C[c] = C; p.status[c] = 1; p.points[c] = (unsigned long long)npts; }
+            return;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_fold_eval(const float* __restrict__ A, const int32_t* __restrict__ beta,
                                                         const float* __restrict__ C, int mode, int c,
                                                         int has_res, const int32_t* __restrict__ acc,
@@ -192,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void k_fold_eval(const float* __restrict_
     const float a = A[c], cc = C[c];
     const int b = beta[c];
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
-        codes[i] = qnn_fold_code(256 * acc[i] + b, a, cc, mode, has_res != 0, has_res ? sc[i] : 0);
+        codes[i] = qnn_fold_code(mode == 3 ? acc[i] : 256 * acc[i] + b, a, cc, mode, has_res != 0, has_res ? sc[i] : 0);
 }
 
 }  // namespace
@@ -201,9 +254,18 @@ extern "C" int qnn_fold_prepare(const qnn_weights_t* w, int x_store, int x_bits,
                                 qnn_fold_t** out) {
     QNN_REQUIRE(w && epi && out, QNN_EINVAL, "qnn_fold_prepare: null pointer");
     *out = nullptr;
-    QNN_REQUIRE(w->store == QNN_STORE_I4 && w->d_mfma && x_store == QNN_STORE_I4, QNN_EUNSUPPORTED,
+    const bool image = x_store == QNN_STORE_U8 || x_store == QNN_STORE_F32_IMAGE;
+    if (image) x_store = QNN_STORE_U8;
+    QNN_REQUIRE(image || (w->store == QNN_STORE_I4 && w->d_mfma && x_store == QNN_STORE_I4), QNN_EUNSUPPORTED,
                 "qnn_fold_prepare: needs weights prepacked for QNN_STORE_I4 with a matrix-pipe image and QNN_STORE_I4 input "
                 "(store=%d x_store=%d)", w->store, x_store);
+    if (image) {
+        QNN_REQUIRE(w->d_wq && w->kh == 3 && w->kw == 3 && w->cin == 3 && w->stride == 1 &&
+                        (w->wkind == QNN_W_BINARY || w->wkind == QNN_W_TERNARY || (w->wkind == QNN_W_QUANT && w->wbits <= 4)) &&
+                        !epi->res, QNN_EUNSUPPORTED,
+                    "qnn_fold_prepare: the image entry is folded for 3x3 stride-1 layers on 3 channels with weights of <= 4 bits");
+        x_bits = 0;
+    } else
     QNN_REQUIRE(x_bits >= 1 && x_bits <= 4, QNN_EINVAL, "qnn_fold_prepare: x_bits=%d", x_bits);
     QNN_REQUIRE(epi->fn == QNN_FN_QUANTIZED_TANH && epi->act_bits == 4 && epi->out_store == QNN_STORE_I4, QNN_EUNSUPPORTED,
                 "qnn_fold_prepare: only quantized_tanh with 4-bit codes stored as QNN_STORE_I4 is folded (fn=%d act_bits=%d "
@@ -269,11 +331,21 @@ extern "C" int qnn_fold_prepare(const qnn_weights_t* w, int x_store, int x_bits,
     int32_t* h_status = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)w->cout);
     unsigned long long* h_points = (unsigned long long*)malloc(sizeof(unsigned long long) * (size_t)w->cout);
     if (!h_status || !h_points) { free(h_status); free(h_points); qnn_set_error("qnn_fold_prepare: out of host memory"); return fail(QNN_ENOMEM); }
+    FoldProblemU8 pu;
+    memset((void*)&pu, 0, sizeof(pu));
+    if (image) {
+        pu.e = p.e;
+        pu.e.scale = 255.0f * (float)(1 << w->wshift);
+        pu.wq = w->d_wq; pu.K = w->kh * w->kw * w->cin; pu.wscale = (float)(1 << w->wshift);
+        pu.A = f->d_a; pu.C = f->d_c; pu.status = d_status; pu.dom = d_dom; pu.points = d_points;
+        (void)hipMemsetAsync(f->d_b, 0, sizeof(int32_t) * w->cout, s);
+    }
     // the "bits" form first (one instruction fewer per value; needs the accumulators inside +-2^22 on every channel),
-    // the conversion form if some channel has no fold in it
-    for (int mode = 2; mode >= 1; --mode) {
+    // the conversion form if some channel has no fold in it; the image entry has its own single form (mode 3)
+    for (int mode = image ? 3 : 2; mode >= (image ? 3 : 1); --mode) {
         p.mode = mode;
-        hipLaunchKernelGGL(k_fold_prepare, dim3((unsigned)w->cout), dim3(kThreads), 0, s, p);
+        if (image) hipLaunchKernelGGL(k_fold_prepare_u8, dim3((unsigned)w->cout), dim3(kThreads), 0, s, pu);
+        else hipLaunchKernelGGL(k_fold_prepare, dim3((unsigned)w->cout), dim3(kThreads), 0, s, p);
         hipError_t he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(h_status, d_status, sizeof(int32_t) * w->cout, hipMemcpyDeviceToHost, s);
         if (he == hipSuccess) he = hipMemcpyAsync(h_status + w->cout, d_dom, sizeof(int32_t) * 2 * w->cout, hipMemcpyDeviceToHost, s);

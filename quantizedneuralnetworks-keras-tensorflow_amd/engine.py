@@ -136,6 +136,7 @@ class FusedModel:
         if first_layer == "auto" and trick is not None:
             first_layer = "exact"            # the faithful output-side trick lives in the VALU kernel family only
         self.first_layer = first_layer
+        self.fold = True                     # folded epilogues where the library proves one (today: the image entry's first layer)
         self._flag = None                    # "auto": this model's own domain-flag word (eager forwards, captured graphs)
         self._exact_now = False              # "auto": the batch being recomputed takes the exact kernel
         self.device = torch.device(device)
@@ -282,7 +283,22 @@ class FusedModel:
         flag = self._own_flag() if (si == 0 and not u8 and self._auto_now()) else None
         return _abi.conv2d(st["w"], cur, x_store, st["x_bits"], N, H, W, st["inv"],
                            st["shift"], st["fn"], st["act_bits"], st["pool"], st["out_store"], out=out,
-                           trick=st["trick"], domain_flag=flag)
+                           trick=st["trick"], domain_flag=flag, fold=self._first_fold(si, x_store))
+
+    def _first_fold(self, si, x_store):
+        """The image entry's folded epilogue (qnn_fold_prepare, mode 3) for the first step when the call takes the byte
+        kernel (uint8 images, "image" / "auto"), prepared once; None where nothing is folded (other stores, other bit
+        widths, float32 output)."""
+        if si != 0 or not self.fold or x_store not in (_abi.STORE_U8, _abi.STORE_F32_IMAGE):
+            return None
+        st = self.steps[0]
+        if "fold0" not in st:
+            st["fold0"] = None
+            if st["kind"] == "conv" and st["fn"] == _abi.FN_QUANTIZED_TANH and st["act_bits"] == 4 and \
+                    st["out_store"] == _abi.STORE_I4 and st["trick"] is None:
+                st["fold0"] = _abi.Fold.try_prepare(st["w"], _abi.STORE_U8, 0, st["inv"], st["shift"], st["fn"], 4,
+                                                    st["out_store"])
+        return st["fold0"]
 
     def _auto_now(self):
         return self.first_layer == "auto" and not self._exact_now and self.steps[0]["x_store"] == _abi.STORE_F32
@@ -324,7 +340,8 @@ class FusedModel:
             bound.append(_abi.BoundStep(st["kind"], st["w"], x_store, st["x_bits"], N, H, W, st["inv"], st["shift"],
                                         st["fn"], st["act_bits"], st["pool"], st["out_store"],
                                         None if si == 0 else cur, None if si == len(self.steps) - 1 else out,
-                                        trick=None if (u8 and si == 0) else st["trick"]))
+                                        trick=None if (u8 and si == 0) else st["trick"],
+                                        fold=self._first_fold(si, x_store) if st["kind"] == "conv" else None))
             cur, H, W = out, H1, W1
         last = len(bound) - 1
         own = self._own_flag().data_ptr() if (self._auto_now() and not u8) else None

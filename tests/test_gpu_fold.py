@@ -179,3 +179,48 @@ def test_residual_engine_with_and_without_folds(nres):
     m0 = engine.ResidualFusedModel(spec, fold=False, first_layer="exact")
     np.testing.assert_array_equal(host(m0(dev(x))), want)
     assert not m0._folds
+
+
+@pytest.mark.parametrize("gamma_sign", [None, -1.0])
+def test_image_entry_first_layer_fold(gamma_sign):
+    """Mode 3: the first layer on image bytes (QNN_STORE_U8 / QNN_STORE_F32_IMAGE).  The folded epilogue reproduces the
+    entry's specification  clip(rint(fma(float(S), A, B)))  on every integer sum S the filter can produce (swept here
+    against the oracle's u8_affine + fma32), and the kernel gives the same bits with and without it."""
+    rng = np.random.default_rng(17)
+    cf = nets.baseline_config(2)
+    op = {"op": "conv", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (3, 3, 3, 64)).astype(F32),
+          "bias": (rng.standard_normal(64) * 0.05).astype(F32), "strides": (1, 1), "padding": "same"}
+    bn = _rand_bn(rng, 64, 27 * 0.33 * 0.33)
+    if gamma_sign is not None:
+        bn["gamma"] = (np.abs(bn["gamma"]) * gamma_sign).astype(F32)
+    w = engine._prepack(op, _abi.STORE_F32, torch.device("cuda"), stride=1, same_pad=True)
+    i, s_ = engine.bn_constants(bn)
+    inv, shift = dev(i), dev(s_)
+    f = _abi.Fold.try_prepare(w, _abi.STORE_U8, 0, inv, shift, _abi.FN_QUANTIZED_TANH, 4, _abi.STORE_I4)
+    assert f is not None and f.mode == 3 and f.usable, (f and (f.mode, f.folded))
+    codes, ws = O.weight_codes(op)
+    codes = codes.reshape(-1, 64)
+    lo, hi = 255 * np.minimum(codes, 0).sum(axis=0), 255 * np.maximum(codes, 0).sum(axis=0)
+    assert f.acc_lo == lo.min() and f.acc_hi == hi.max()
+    A, B = O.u8_affine(op["bias"], bn, 8.0, 255.0 * 2.0 ** ws, 64)
+    total = 0
+    for c in range(64):
+        S = np.arange(lo[c], hi[c] + 1, dtype=np.int32)
+        want = np.clip(np.rint(O.fma32(S.astype(F32), A[c], B[c])), -8, 7).astype(np.int32)
+        np.testing.assert_array_equal(host(f.eval(c, dev(S))), want, err_msg="channel %d" % c)
+        total += S.size
+    assert total == f.points
+    xu8 = nets.synthetic_images_u8(cf, 6, 3)
+    for x in (dev(xu8), dev((xu8.astype(F32) / F32(255)).astype(F32))):
+        store = _abi.STORE_U8 if x.dtype == torch.uint8 else _abi.STORE_F32_IMAGE
+        outs = []
+        for fold in (None, f):
+            y, hp, wp = _abi.conv2d(w, x, store, 0, 6, 32, 32, inv, shift, _abi.FN_QUANTIZED_TANH, 4, 2, _abi.STORE_I4, fold=fold)
+            outs.append(host(_abi.unpack(y, 6 * hp * wp, 64, _abi.STORE_I4, 4)))
+        np.testing.assert_array_equal(outs[0], outs[1])
+        want = O.maxpool2d(O.u8_conv_group(xu8, op, bn, Q(4)))
+        np.testing.assert_array_equal(outs[1].reshape(want.shape), want)
+    # a fold of the image entry is refused on the exact float32 call of the same layer
+    with pytest.raises(_abi.QnnError, match="fold handle was prepared for another"):
+        _abi.conv2d(w, dev((xu8.astype(F32) / F32(255)).astype(F32)), _abi.STORE_F32, 0, 6, 32, 32, inv, shift,
+                    _abi.FN_QUANTIZED_TANH, 4, 2, _abi.STORE_I4, fold=f)
