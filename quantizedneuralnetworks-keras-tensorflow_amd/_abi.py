@@ -265,6 +265,39 @@ def softmax(x, out=None):
     return y
 
 
+# Handles released while a HIP stream capture is in progress (Python's cycle collector can run a __del__ anywhere, e.g.
+# inside `with torch.cuda.graph(g)`): hipFree is not permitted during a capture and would invalidate it, so the handle is
+# parked here and freed at the next safe point (the next handle creation, or release_deferred()).
+_deferred = []
+
+
+def _release(fn_name, handle):
+    if not (handle and handle.value) or _lib is None:
+        return
+    try:
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    except Exception:
+        capturing = False
+    if capturing:
+        _deferred.append((fn_name, handle.value))
+    else:
+        getattr(_lib, fn_name)(handle)
+
+
+def release_deferred():
+    """Free the handles whose owners died during a stream capture (no-op while a capture is in progress)."""
+    if not _deferred or _lib is None:
+        return
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+    except Exception:
+        return
+    while _deferred:
+        fn_name, value = _deferred.pop()
+        getattr(_lib, fn_name)(ctypes.c_void_p(value))
+
+
 class Weights:
     """Owner of an opaque qnn_weights_t handle."""
 
@@ -282,6 +315,7 @@ class Weights:
         self.stride = stride
         self.same_pad = same_pad
         self.handle = ctypes.c_void_p(None)
+        release_deferred()
         check(load().qnn_prepack_weights(wkind, wbits, float(H), ptr(kernel), kh, kw, cin, cout,
                                          ptr(bias), stride, 1 if same_pad else 0, store,
                                          stream_ptr(), ctypes.byref(self.handle)),
@@ -301,9 +335,8 @@ class Weights:
 
     def __del__(self):
         try:
-            if self.handle and self.handle.value and _lib is not None:
-                _lib.qnn_free_weights(self.handle)
-                self.handle = ctypes.c_void_p(None)
+            _release("qnn_free_weights", self.handle)
+            self.handle = ctypes.c_void_p(None)
         except Exception:
             pass
 
@@ -337,6 +370,7 @@ class Fold:
                  res_bits=0, post_scale=1.0):
         self._keep = (w, bn_inv, bn_shift)
         self.handle = ctypes.c_void_p(None)
+        release_deferred()
         epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, 1, out_store, res, res_store, res_bits, post_scale)
         rc = load().qnn_fold_prepare(w.handle, x_store, x_bits, ctypes.byref(epi), stream_ptr(), ctypes.byref(self.handle))
         self.rc = rc
@@ -371,9 +405,8 @@ class Fold:
 
     def __del__(self):
         try:
-            if self.handle and self.handle.value and _lib is not None:
-                _lib.qnn_fold_free(self.handle)
-                self.handle = ctypes.c_void_p(None)
+            _release("qnn_fold_free", self.handle)
+            self.handle = ctypes.c_void_p(None)
         except Exception:
             pass
 
@@ -420,12 +453,12 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
 
 
 
-def conv2d_dense(wc, wd, x, x_store, x_bits, N, H, W, c_inv, c_shift, c_fn, c_act_bits, d_inv, d_shift, out=None):
+def conv2d_dense(wc, wd, x, x_store, x_bits, N, H, W, c_inv, c_shift, c_fn, c_act_bits, d_inv, d_shift, out=None, fold=None):
     """qnn_conv2d_dense_forward: the last conv group (2x2 pool, packed int4 codes) and the dense head behind it in one
     launch.  Returns the (N, units) float32 logits, or None when no fused kernel covers the pair (QNN_EUNSUPPORTED)."""
     units = wd.shape[3]
     y = out if out is not None else torch.empty((N, units), dtype=torch.float32, device=x.device)
-    ec = make_epilogue(c_inv, c_shift, c_fn, c_act_bits, 2, STORE_I4)
+    ec = make_epilogue(c_inv, c_shift, c_fn, c_act_bits, 2, STORE_I4, fold=fold)
     ed = make_epilogue(d_inv, d_shift, FN_NONE, 0, 1, STORE_F32)
     rc = load().qnn_conv2d_dense_forward(wc.handle, wd.handle, ptr(x), x_store, x_bits, N, H, W, ctypes.byref(ec),
                                          ctypes.byref(ed), ptr(y), stream_ptr())
@@ -438,9 +471,9 @@ def conv2d_dense(wc, wd, x, x_store, x_bits, N, H, W, c_inv, c_shift, c_fn, c_ac
 class BoundHead:
     """qnn_conv2d_dense_forward with everything bound once (see BoundStep)."""
 
-    def __init__(self, wc, wd, x_store, x_bits, N, H, W, c_inv, c_shift, c_fn, c_act_bits, d_inv, d_shift, x):
-        self._keep = (wc, wd, c_inv, c_shift, d_inv, d_shift, x)
-        self._ec = make_epilogue(c_inv, c_shift, c_fn, c_act_bits, 2, STORE_I4)
+    def __init__(self, wc, wd, x_store, x_bits, N, H, W, c_inv, c_shift, c_fn, c_act_bits, d_inv, d_shift, x, fold=None):
+        self._keep = (wc, wd, c_inv, c_shift, d_inv, d_shift, x, fold)
+        self._ec = make_epilogue(c_inv, c_shift, c_fn, c_act_bits, 2, STORE_I4, fold=fold)
         self._ed = make_epilogue(d_inv, d_shift, FN_NONE, 0, 1, STORE_F32)
         self._x = x.data_ptr()
         self._fn = load().qnn_conv2d_dense_forward

@@ -1,6 +1,7 @@
 // Persistent short-K int8 MFMA kernels: filter slice resident in LDS (k_conv_mfma_wres) and activations
 // loaded straight into operand registers (k_conv_mfma_areg).  Dispatch: qnn_try_launch_mfma (qnn_mfma.hip).
 #include "qnn_mfma_common.h"
+#include "qnn_fold.h"
 
 namespace {
 
@@ -776,7 +777,10 @@ __global__ __launch_bounds__(256, (OUT == QNN_STORE_F32 ? 2 : 3)) void k_conv_mf
 // which permutes the residues -- 16 distinct slots of the 256-byte bank row either way, conflict-free.
 // Filters: LDS, shared by the workgroup's NW waves (as areg).  No barrier in the main loop: a wave's LDS operations
 // execute in order, and the region is its own.
-template <int TWP, int NW, bool HEAD>
+// FOLD (round 4): the epilogue as qnn_fold.h's "bits" form -- the accumulators start from the channel's offset (which carries
+// the float's bit pattern), the 2x2 window is pooled on the raw integers as before, and a pooled value costs one v_fma_f32 +
+// half a v_cvt_pknorm_i16_f32 + half a packing instruction instead of cvt, add, mul, add, add, v_med3 and a shift-add.
+template <int TWP, int NW, bool HEAD, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64, 1) void k_conv_mfma_halo(MfmaGeom mg, EpiArgs e, const uint8_t* __restrict__ x,
                                                                const uint8_t* __restrict__ wq8, void* __restrict__ y,
                                                                int ntiles, FastDiv fd_tpi, int txn, FastDiv fd_txn,
@@ -825,6 +829,15 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_mfma_halo(MfmaGeom mg, EpiA
         fe[b].nshift = __fmul_rn(ke[b].shift, mfold);
     }
     const bool all_pos = !__any((int)(ke[0].neg || ke[1].neg));
+    float fda[2] = {0.0f, 0.0f}, fdc[2] = {0.0f, 0.0f};
+    int fdb[2] = {0, 0};
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = nbase + b * 32 + li;
+            fda[b] = e.fold_a[c]; fdc[b] = e.fold_c[c]; fdb[b] = e.fold_b[c];
+        }
+    }
     int hu = 0;
     float hbias = 0.0f, hinv = 1.0f, hshift = 0.0f;
     if constexpr (HEAD) {
@@ -923,6 +936,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_mfma_halo(MfmaGeom mg, EpiA
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             float tv[8];
+            int pv[8];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -930,21 +944,31 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_mfma_halo(MfmaGeom mg, EpiA
                     const int i0 = acc[a][b][4 * g4], i1 = acc[a][b][4 * g4 + 1];
                     const int i2 = acc[a][b][4 * g4 + 2], i3 = acc[a][b][4 * g4 + 3];
                     const int mx = max(max(i0, i1), max(i2, i3));
-                    if (all_pos) {
-                        tv[a * 4 + g4] = bn(mx, fe[b]);
-                    } else {
+                    int pooled = mx;
+                    if (!all_pos) {
                         const int mn = min(min(i0, i1), min(i2, i3));
-                        tv[a * 4 + g4] = bn(ke[b].neg ? mn : mx, fe[b]);
+                        pooled = ke[b].neg ? mn : mx;
                     }
+                    if constexpr (FOLD) pv[a * 4 + g4] = pooled;
+                    else tv[a * 4 + g4] = bn(pooled, fe[b]);
                 }
+            uint32_t Q;                                  // eight two's-complement codes, nibble j = value j
+            if constexpr (FOLD) {
+                uint32_t tp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tp[j] = qnn_fold_pair_bits(pv[j], pv[j + 4], fda[b], fda[b], fdc[b], fdc[b]);
+                const uint32_t uo = __builtin_amdgcn_perm(tp[3], tp[1], 0x07030501u);
+                const uint32_t ue = __builtin_amdgcn_perm(tp[2], tp[0], 0x07030501u);
+                Q = (uo & 0xF0F0F0F0u) | ((ue >> 4) & 0x0F0F0F0Fu);
+            } else {
+                Q = pack_scaled<4, 8>(tv, e.act_m, binary) ^ 0x88888888u;
+            }
             if constexpr (HEAD) {
-                const uint32_t Q = pack_scaled<4, 8>(tv, e.act_m, binary) ^ 0x88888888u;
                 const uint32_t* trow = reinterpret_cast<const uint32_t*>(smem + HTAB) + lane * 2 + b;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) dacc[u] = __builtin_amdgcn_sdot8((int)Q, (int)trow[u * 128], dacc[u], false);
             } else {
-                const uint32_t P = pack_scaled<4, 8>(tv, e.act_m, binary);
-                ytile[lane_off + b * 4] = transpose_nib8(P, ke[0]) ^ 0x88888888u;
+                ytile[lane_off + b * 4] = transpose_nib8(Q, ke[0]);       // (a permutation of nibbles: the codes pass through)
             }
         }
         if constexpr (HEAD) {
@@ -991,7 +1015,8 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_mfma_halo(MfmaGeom mg, EpiA
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     if (st == 0) {
-                        const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        const int z0 = FOLD ? fdb[b] : 0;      // the fold's offset (with the magic constant): this lane's channel
+                        const v16i z = {z0, z0, z0, z0, z0, z0, z0, z0, z0, z0, z0, z0, z0, z0, z0, z0};
                         acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[st & 1][a], fb[st & 1][b], z, 0, 0, 0);
                     } else {
                         acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[st & 1][a], fb[st & 1][b], acc[a][b], 0, 0, 0);
@@ -1004,9 +1029,9 @@ __global__ __launch_bounds__(NW * 64, 1) void k_conv_mfma_halo(MfmaGeom mg, EpiA
     }
 }
 
-template <int TWP, int NW, bool HEAD>
-void launch_halo_one(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, const HeadArgs& hd,
-                     hipStream_t s) {
+template <int TWP, int NW, bool HEAD, bool FOLD = false>
+void launch_halo_one_f(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, const HeadArgs& hd,
+                       hipStream_t s) {
     const ConvGeom& g = mg.g;
     constexpr int THP = 16 / TWP;
     const int txn = g.Wp / TWP, tyn = g.Hp / THP;
@@ -1019,14 +1044,22 @@ void launch_halo_one(const MfmaGeom& mg, const EpiArgs& e, const void* x, const 
     const int cap = 256 / ny > 0 ? 256 / ny : 1;             // one resident workgroup per CU
     if (gx > cap) gx = cap;
     static const bool lds_ok = [] {
-        (void)hipFuncSetAttribute((const void*)k_conv_mfma_halo<TWP, NW, HEAD>,
+        (void)hipFuncSetAttribute((const void*)k_conv_mfma_halo<TWP, NW, HEAD, FOLD>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)lds_ok;
-    hipLaunchKernelGGL((k_conv_mfma_halo<TWP, NW, HEAD>), dim3((unsigned)gx, (unsigned)ny), dim3(NW * 64), lds, s, mg, e,
+    hipLaunchKernelGGL((k_conv_mfma_halo<TWP, NW, HEAD, FOLD>), dim3((unsigned)gx, (unsigned)ny), dim3(NW * 64), lds, s, mg, e,
                        (const uint8_t*)x, w, y, ntiles, qnn_fastdiv((uint32_t)tpi), txn, qnn_fastdiv((uint32_t)txn),
                        (uint32_t)(g.H * g.W * 32), hd);
+}
+
+// a usable fold in the "bits" form (qnn_fold.h mode 2: e.fold_c set) takes the folded epilogue
+template <int TWP, int NW, bool HEAD>
+void launch_halo_one(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint8_t* w, void* y, const HeadArgs& hd,
+                     hipStream_t s) {
+    if (e.fold_a && e.fold_c && e.fn == QNN_FN_QUANTIZED_TANH) launch_halo_one_f<TWP, NW, HEAD, true>(mg, e, x, w, y, hd, s);
+    else launch_halo_one_f<TWP, NW, HEAD, false>(mg, e, x, w, y, hd, s);
 }
 
 // 0 = launched.  The pooled map must tile into 8 x 2 or 4 x 4 rectangles; everything else stays on k_conv_mfma_areg.

@@ -262,7 +262,8 @@ class FusedModel:
             return None
         c, d = self.steps[-2], self.steps[-1]
         y = _abi.conv2d_dense(c["w"], d["w"], cur, c["x_store"], c["x_bits"], N, H, W, c["inv"], c["shift"], c["fn"],
-                              c["act_bits"], d["inv"], d["shift"], out=out)
+                              c["act_bits"], d["inv"], d["shift"], out=out,
+                              fold=self._first_fold(len(self.steps) - 2, c["x_store"]))
         if y is None:
             self._head_no[(H, W)] = True     # no fused kernel for this geometry: do not ask again
         return y
@@ -286,19 +287,26 @@ class FusedModel:
                            trick=st["trick"], domain_flag=flag, fold=self._first_fold(si, x_store))
 
     def _first_fold(self, si, x_store):
-        """The image entry's folded epilogue (qnn_fold_prepare, mode 3) for the first step when the call takes the byte
-        kernel (uint8 images, "image" / "auto"), prepared once; None where nothing is folded (other stores, other bit
-        widths, float32 output)."""
-        if si != 0 or not self.fold or x_store not in (_abi.STORE_U8, _abi.STORE_F32_IMAGE):
+        """The folded epilogue of step `si` for a call with input store `x_store` (qnn_fold_prepare: proven equal to the
+        float32 chain / the image entry's specification on the layer's whole accumulator domain), prepared once per
+        (step, form); None where nothing is folded (other stores or bit widths, float32 output, the faithful trick).
+          step 0 on image bytes (uint8, "image" / "auto")  -> the image entry's form (mode 3);
+          int4 -> int4 layers with quantized_tanh(4)          -> the matrix-pipe forms (modes 1 / 2)."""
+        st = self.steps[si]
+        if not self.fold or st["kind"] != "conv" or st["fn"] != _abi.FN_QUANTIZED_TANH or st["act_bits"] != 4 or \
+                st["out_store"] != _abi.STORE_I4 or st["trick"] is not None:
             return None
-        st = self.steps[0]
-        if "fold0" not in st:
-            st["fold0"] = None
-            if st["kind"] == "conv" and st["fn"] == _abi.FN_QUANTIZED_TANH and st["act_bits"] == 4 and \
-                    st["out_store"] == _abi.STORE_I4 and st["trick"] is None:
-                st["fold0"] = _abi.Fold.try_prepare(st["w"], _abi.STORE_U8, 0, st["inv"], st["shift"], st["fn"], 4,
-                                                    st["out_store"])
-        return st["fold0"]
+        if si == 0 and x_store in (_abi.STORE_U8, _abi.STORE_F32_IMAGE):
+            key, args = "fold_img", (_abi.STORE_U8, 0)
+        elif x_store == _abi.STORE_I4:
+            key, args = "fold_i4", (_abi.STORE_I4, st["x_bits"])
+        else:
+            return None
+        if key not in st:
+            if torch.cuda.is_current_stream_capturing():
+                return None                  # preparing synchronises: never inside a capture (the chain gives the same bits)
+            st[key] = _abi.Fold.try_prepare(st["w"], args[0], args[1], st["inv"], st["shift"], st["fn"], 4, st["out_store"])
+        return st[key]
 
     def _auto_now(self):
         return self.first_layer == "auto" and not self._exact_now and self.steps[0]["x_store"] == _abi.STORE_F32
@@ -332,7 +340,8 @@ class FusedModel:
                 if y is not None:            # conv group + classifier in one launch: the plan ends here
                     c, d = self.steps[-2], self.steps[-1]
                     bound.append(_abi.BoundHead(c["w"], d["w"], c["x_store"], c["x_bits"], N, H, W, c["inv"], c["shift"],
-                                                c["fn"], c["act_bits"], d["inv"], d["shift"], cur))
+                                                c["fn"], c["act_bits"], d["inv"], d["shift"], cur,
+                                                fold=self._first_fold(len(self.steps) - 2, c["x_store"])))
                     cur = y
                     break
             out, H1, W1 = self.run_step(si, cur, N, H, W)
@@ -803,10 +812,10 @@ class ResidualFusedModel:
             if self.fold and xs == _abi.STORE_I4 and out_store == _abi.STORE_I4 and fn == _abi.FN_QUANTIZED_TANH and ab == 4 \
                     and (res is None or (isinstance(res, _Packed) and res.store == _abi.STORE_I4 and res.bits == 4)):
                 fkey = (ci, bn_i, xb, None if res is None else float(post_scale))
-                if fkey not in self._folds:
-                    self._folds[fkey] = _abi.Fold.try_prepare(
+                if fkey not in self._folds and not torch.cuda.is_current_stream_capturing():
+                    self._folds[fkey] = _abi.Fold.try_prepare(          # (synchronises: never inside a capture)
                         w, xs, xb, inv, shift, fn, ab, out_store, **{k: v for k, v in rkw.items()})
-                fold = self._folds[fkey]
+                fold = self._folds.get(fkey)
 
             def launch():
                 return _abi.conv2d(w, xin, xs, xb, N, H, W, inv, shift, fn, ab, 1, out_store, fold=fold, domain_flag=dflag,

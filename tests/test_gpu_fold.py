@@ -224,3 +224,40 @@ def test_image_entry_first_layer_fold(gamma_sign):
     with pytest.raises(_abi.QnnError, match="fold handle was prepared for another"):
         _abi.conv2d(w, dev((xu8.astype(F32) / F32(255)).astype(F32)), _abi.STORE_F32, 0, 6, 32, 32, inv, shift,
                     _abi.FN_QUANTIZED_TANH, 4, 2, _abi.STORE_I4, fold=f)
+
+
+@pytest.mark.parametrize("gamma_sign", [None, 1.0, -1.0])
+@pytest.mark.parametrize("hw,n", [((16, 16), 5), ((8, 8), 9), ((32, 32), 2)])
+def test_pooled_64_channel_layers_with_the_fold(hw, n, gamma_sign):
+    """k_conv_mfma_halo (CIFAR B0 / C0: 64 -> 64 channels, 2x2 max pool) with the folded epilogue in its "bits" form: pooling
+    on the raw accumulators that carry the offset, same bits as the float32 chain and as the oracle; also through the fused
+    conv + classifier launch (qnn_conv2d_dense_forward)."""
+    rng = np.random.default_rng(hw[0] + n)
+    H, W = hw
+    x, xp = _packed_codes(rng, n, H, W, 64)
+    op, bn = _layer(rng, 64, 64, 3, True, 1, gamma_sign)
+    if gamma_sign is not None:       # BN scales away from zero, as trained ones are: the thresholds then lie inside the "bits"
+        bn["gamma"] = (np.sign(bn["gamma"]) * np.maximum(np.abs(bn["gamma"]), 0.5)).astype(F32)      # form's exact range
+    w, inv, shift, f = _prep(op, bn, False)
+    assert f is not None and f.usable and (f.mode == 2 or gamma_sign is None), (f.folded, f.mode)
+    # (a channel whose BN scale is nearly zero spreads its thresholds beyond +-2^22 accumulator units: the handle is then
+    # in the conversion form, which this kernel does not take -- it keeps the float32 chain; same bits either way)
+    outs = []
+    for fold in (None, f):
+        y, hp, wp = _abi.conv2d(w, xp, _abi.STORE_I4, 4, n, H, W, inv, shift, _abi.FN_QUANTIZED_TANH, 4, 2, _abi.STORE_I4, fold=fold)
+        assert _abi.last_kernel() == "mfma_i4_halo64x64", _abi.last_kernel()
+        outs.append(host(_abi.unpack(y, n * hp * wp, 64, _abi.STORE_I4, 4)).reshape(n, hp, wp, 64))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    v = O.quantized_conv2d_call(x, op["kernel"], op["bias"], nb=4)
+    v = O.batchnorm_inference(v, bn["gamma"], bn["beta"], bn["mean"], bn["var"], bn["eps"])
+    np.testing.assert_array_equal(outs[1], O.maxpool2d(O.quantized_tanh(v, 4)))
+    if hw == (8, 8):                                     # 4 x 4 pooled map: the classifier rides in the same launch
+        dense = {"op": "dense", "kind": "quantized", "nb": 4, "kernel": rng.uniform(-1, 1, (1024, 10)).astype(F32),
+                 "bias": (rng.standard_normal(10) * 0.1).astype(F32)}
+        wd = engine._prepack(dense, _abi.STORE_I4, torch.device("cuda"))
+        got = [host(_abi.conv2d_dense(w, wd, xp, _abi.STORE_I4, 4, n, H, W, inv, shift, _abi.FN_QUANTIZED_TANH, 4, None, None,
+                                      fold=fold)) for fold in (None, f)]
+        assert _abi.last_kernel() == "mfma_i4_halo64x64+dense", _abi.last_kernel()
+        np.testing.assert_array_equal(got[0], got[1])
+        want = O.quantized_dense_call(O.maxpool2d(O.quantized_tanh(v, 4)).reshape(n, -1), dense["kernel"], dense["bias"], nb=4)
+        np.testing.assert_array_equal(got[1], want)

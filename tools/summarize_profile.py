@@ -55,8 +55,11 @@ TAG_PATTERNS = [
     (r"^mfma_i(\d)_wres256x64$", r"^k_conv_mfma_wres<\1,"),
     (r"^mfma_i4_small_c(\d+)$", r"^k_conv_mfma_small<\1,"),
     (r"^mfma_i8x3_first_fixed$", r"^k_conv_first_fixed<"),
-    (r"^mfma_i8_first_u8$", r"^k_conv_first_u8<\d, \d, \w+, (false|0)>"),
-    (r"^mfma_i8_first_img255$", r"^k_conv_first_u8<\d, \d, \w+, (true|1)>"),
+    (r"^mfma_i8_first_u8$", r"^k_conv_first_u8(_full)?<\d, \d, \w+, (false|0)(, \w+)?>"),
+    (r"^mfma_i8_first_img255$", r"^k_conv_first_u8(_full)?<\d, \d, \w+, (true|1)(, \w+)?>"),
+    (r"^strip_i4_c16_lds:res_none$", r"^k_conv_strip16_lds<(false|0),"),
+    (r"^strip_i4_c16_lds:res_packed$", r"^k_conv_strip16_lds<(true|1),"),
+    (r"^strip_i4_c16_lds$", r"^k_conv_strip16_lds<"),
     (r"^strip_i4_c(\d+)_s2(:res_\w+)?$", r"^k_conv_strip_s2<\1,"),
     (r"^strip_i4_c(\d+):res_none$", r"^k_conv_strip<\1, \d, 0,"),
     (r"^strip_i4_c(\d+):res_packed$", r"^k_conv_strip<\1, \d, 1,"),
