@@ -43,7 +43,9 @@
 #define QNN_STRIP32_WPS 3        // Cin 32: 118-128 VGPRs, the float32-shortcut variant spilled at 4 per SIMD
 #endif
 #ifndef QNN_STRIP64_WPS
-#define QNN_STRIP64_WPS 2        // Cin 64 (two 32-channel halves per strip): 164-200 VGPRs, spills at 3 per SIMD
+#define QNN_STRIP64_WPS 1        // Cin 64 (two 32-channel halves per strip): 164-200 VGPRs, spills at 3 per SIMD.  Round 4: ONE
+                                 // wave per SIMD with a six-row ring: the layer alone is as fast as with two (11.3 / 13.2 us),
+                                 // and the other batch's kernels find room beside it: ResNet-224 end to end 77.4 -> 79.5 K img/s
 #endif
 #ifndef QNN_STRIP16_DEPTH
 #define QNN_STRIP16_DEPTH 3      // input rows requested ahead of the row being computed (see the ring in k_conv_strip)
@@ -52,7 +54,7 @@
 #define QNN_STRIP32_DEPTH 3
 #endif
 #ifndef QNN_STRIP64_DEPTH
-#define QNN_STRIP64_DEPTH 3
+#define QNN_STRIP64_DEPTH 6
 #endif
 
 namespace {

@@ -37,14 +37,14 @@ constexpr int kXSlot = 2048, kSSlot = 1024; // bytes of a six-row group in LDS: 
 constexpr int kXRow = 320, kSRow = 128;     // bytes per staged input row (20 widened pixels) / shortcut row (16 pixels)
 
 // Occupancy (round 4, 64 x 224 x 224: 21.9 us at 6 waves per SIMD, 19.5 / 18.4 / 16.6 / 18.0 / 26.6 us at 5 / 4 / 3 / 2 / 1): the
-// persistent grid runs THREE waves per SIMD -- each wave then owns ~76 rows of a strip instead of ~38 (half the ring
+// persistent grid runs TWO to THREE waves per SIMD -- each wave then owns 76-112 rows of a strip instead of ~38 (fewer ring
 // fills) and three waves already cover one another's LDS and matrix-pipe latencies; the register bound is left at four.
 #ifndef QNN_S16_BOUNDS
 #define QNN_S16_BOUNDS 4
 #endif
 #ifndef QNN_S16_WPS
-#define QNN_S16_WPS 3
-#endif
+#define QNN_S16_WPS 2            // (3 is the fastest for the layer alone, 16.6 against 18.0 us; with two batches in flight 2 leaves
+#endif                           // the other batch's kernels more room: ResNet-224 end to end 77.4 -> 78.9 K img/s)
 template <bool RES, int FOLD>
 __global__ __launch_bounds__(256, QNN_S16_BOUNDS) void k_conv_strip16_lds(MfmaGeom mg, EpiArgs e, const uint8_t* __restrict__ x,
                                                              const uint8_t* __restrict__ wq8, void* __restrict__ y,
