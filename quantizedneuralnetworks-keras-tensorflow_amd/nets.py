@@ -272,11 +272,12 @@ class Model:
     test_resnet.py:63-81), reduced to the inference surface: predict / evaluate / summary /
     set of weights, executing on the fused GPU engines."""
 
-    def __init__(self, cf, spec, device="cuda", first_layer="auto", lanes=2):
+    def __init__(self, cf, spec, device="cuda", first_layer="auto", lanes=None):
         """first_layer: kernel for float32 images ("auto" | "exact" | "image" | "fixed", engine.FusedModel; "auto", the
         default, takes every float tensor like the reference's call(): the byte kernel where a batch is image bytes /
         255, the exact kernel where it is not); uint8 images always take the typed QNN_STORE_U8 entry.  lanes: batches
-        kept in flight by predict() (engine.Pipelined)."""
+        kept in flight by predict() (engine.Pipelined; default 2 for the chain engine, 3 for the residual engine, whose
+        kernels run at one to three waves per SIMD and leave room for a third batch: +5 % on the ImageNet-224 ResNet)."""
         from . import engine, _abi
         self.cf, self.spec = cf, spec
         try:
@@ -285,7 +286,7 @@ class Model:
             self.engine = engine.ResidualFusedModel(spec, device,
                                                     first_layer=first_layer if first_layer in ("auto", "image") else "exact")
         self.layers = [op for op in spec if op["op"] in ("conv", "dense")]
-        self.lanes = int(lanes)
+        self.lanes = int(lanes) if lanes is not None else (2 if isinstance(self.engine, engine.FusedModel) else 3)
         self.upload_batches = 8              # predict() on a host array: batches uploaded (and resident) at a time
         self._pipes = {}
 
@@ -370,7 +371,7 @@ class Model:
         print_fn("Total params: %d   engine: %s" % (self.count_params(), type(self.engine).__name__))
 
 
-def build_model(cf, seed=0, device="cuda", first_layer="auto", lanes=2):
+def build_model(cf, seed=0, device="cuda", first_layer="auto", lanes=None):
     """model_factory.py:18-72: config -> model (synthetic weights; use spec_from_keras_npz +
     Model(cf, spec) to run an imported checkpoint)."""
     return Model(cf, build_spec(cf, seed), device, first_layer=first_layer, lanes=lanes)
