@@ -40,7 +40,8 @@
 #define QNN_STRIP16_WPS 6        // waves per SIMD (= persistent workgroups per CU): Cin 16 needs 51-67 VGPRs
 #endif
 #ifndef QNN_STRIP32_WPS
-#define QNN_STRIP32_WPS 3        // Cin 32: 118-128 VGPRs, the float32-shortcut variant spilled at 4 per SIMD
+#define QNN_STRIP32_WPS 1        // Cin 32: 118-128 VGPRs.  Round 4: ONE wave per SIMD with a six-row ring (3 before): same layer time,
+                                 // room for the other batches' kernels: ResNet-224 with three batches in flight 85.1 -> 87.0 K img/s
 #endif
 #ifndef QNN_STRIP64_WPS
 #define QNN_STRIP64_WPS 1        // Cin 64 (two 32-channel halves per strip): 164-200 VGPRs, spills at 3 per SIMD.  Round 4: ONE
@@ -51,7 +52,7 @@
 #define QNN_STRIP16_DEPTH 3      // input rows requested ahead of the row being computed (see the ring in k_conv_strip)
 #endif
 #ifndef QNN_STRIP32_DEPTH
-#define QNN_STRIP32_DEPTH 3
+#define QNN_STRIP32_DEPTH 6
 #endif
 #ifndef QNN_STRIP64_DEPTH
 #define QNN_STRIP64_DEPTH 6
