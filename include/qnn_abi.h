@@ -129,6 +129,25 @@ typedef struct qnn_fold qnn_fold_t;         /* opaque: one layer's epilogue fold
  * trick_s != 0 bypasses the matrix-pipe kernels.  The INPUT-side trick (163-165) perturbs grid-valued inputs by at most
  * one ulp and would make the contraction a float32 problem; it stays the identity.
  */
+/*
+ * A projection shortcut computed INSIDE the launch (ABI 4).  models/resnet.py:117-124: the first block of a stage adds
+ * the block input through a 1x1, strides-2 QuantizedConv2D (no BN, no activation) to the BN output of the block's second
+ * 3x3 convolution.  As two launches that float32 shortcut is written and read once (8x the bytes of the packed block
+ * input it is computed from: 103 MB against 12.8 MB per 64 images at 224^2 -> 112^2); as `proj` of the second
+ * convolution's epilogue the launch reads the block input itself -- output pixel (y, x) takes input pixel (2y, 2x) --
+ * and forms   float32(sum_k code_x code_w) * 2^-(wshift + x_bits - 1) [+ bias]   per output value: bit for bit what
+ * qnn_conv2d_forward(w, x, out_store = QNN_STORE_F32, no BN) stores, then added like a QNN_STORE_F32 `res`
+ * (post_scale applies).  Supported where the row-walking strip kernel runs the layer (3x3 stride-1 int4 layer with
+ * cin = cout in {32, 64}, packed int4 output, w->cin == cin / 2): anything else returns QNN_EUNSUPPORTED -- the caller
+ * keeps the two-launch form.  `res` and `fold` must be NULL.
+ */
+typedef struct qnn_projection {
+    const qnn_weights_t* w;  /* prepacked 1x1 kernel, strides 2, QNN_STORE_I4; w->cout == the layer's cout            */
+    const void* x;           /* DEVICE: the block input, packed int4 codes, N x H x W x w->cin                        */
+    int32_t H, W;            /* its spatial size; ceil(H / 2) x ceil(W / 2) must be the layer's output size           */
+    int32_t x_bits;          /* value = code / 2^(x_bits - 1)                                                         */
+} qnn_projection_t;
+
 typedef struct qnn_epilogue {
     const float* bn_inv;     /* [cout] or NULL                                  */
     const float* bn_shift;   /* [cout] or NULL                                  */
@@ -150,6 +169,8 @@ typedef struct qnn_epilogue {
                               * non-zero value there instead of raising the layer's own flag -- one word per
                               * batch in flight lets the caller recompute exactly the affected batch on the
                               * exact kernel (engine "auto" mode).  NULL = the handle's flag (ABI 4)          */
+    const qnn_projection_t* proj;   /* the shortcut as a 1x1 strides-2 convolution of the block input, computed inside
+                                     * the launch (see qnn_projection_t), or NULL (ABI 4)                             */
 } qnn_epilogue_t;
 
 /*

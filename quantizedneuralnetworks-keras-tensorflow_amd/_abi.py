@@ -31,13 +31,20 @@ EXPORTS = [
 ]
 
 
+class Projection(ctypes.Structure):
+    """qnn_projection_t: the shortcut as a 1x1 strides-2 convolution of the block input, computed inside the launch."""
+    _fields_ = [("w", ctypes.c_void_p), ("x", ctypes.c_void_p), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("x_bits", ctypes.c_int32)]
+
+
 class Epilogue(ctypes.Structure):
     _fields_ = [("bn_inv", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
                 ("fn", ctypes.c_int32), ("act_bits", ctypes.c_int32),
                 ("pool", ctypes.c_int32), ("out_store", ctypes.c_int32),
                 ("res", ctypes.c_void_p), ("res_store", ctypes.c_int32), ("res_bits", ctypes.c_int32),
                 ("post_scale", ctypes.c_float), ("trick_c", ctypes.c_float), ("trick_s", ctypes.c_float),
-                ("fold", ctypes.c_void_p), ("flags", ctypes.c_uint32), ("domain_flag", ctypes.c_void_p)]
+                ("fold", ctypes.c_void_p), ("flags", ctypes.c_uint32), ("domain_flag", ctypes.c_void_p),
+                ("proj", ctypes.c_void_p)]
 
 
 class FoldInfo(ctypes.Structure):
@@ -48,6 +55,11 @@ class FoldInfo(ctypes.Structure):
 
 class QnnError(RuntimeError):
     pass
+
+
+class QnnUnsupported(QnnError):
+    """QNN_EUNSUPPORTED from an optional fused form (a projection shortcut computed inside the launch): the caller keeps
+    the form it had."""
 
 
 class NotFusable(QnnError):
@@ -348,15 +360,24 @@ def out_hw(size, k, stride, same_pad):
 
 
 def make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res=None, res_store=STORE_F32,
-                  res_bits=0, post_scale=1.0, trick=None, fold=None, domain_flag=None, flags=None):
+                  res_bits=0, post_scale=1.0, trick=None, fold=None, domain_flag=None, flags=None, proj=None):
     """trick: None (the reference's lr-multiplier identity trick is the identity) or the (c, s) float32 pair of its
-    OUTPUT side, `faithful_trick(klm, promotion)`.  fold: a Fold prepared for exactly this layer and epilogue."""
+    OUTPUT side, `faithful_trick(klm, promotion)`.  fold: a Fold prepared for exactly this layer and epilogue.
+    proj: (weights of the 1x1 strides-2 projection, packed block input, H, W, x_bits) -- the shortcut computed inside the
+    launch (qnn_projection_t); the returned epilogue keeps the descriptor alive as `_proj`."""
     tc, ts = (float(trick[0]), float(trick[1])) if trick is not None else (0.0, 0.0)
-    return Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store,
-                    ptr(res).value, res_store, res_bits, float(post_scale), tc, ts,
-                    fold.handle.value if fold is not None else None,
-                    _default_flags if flags is None else int(flags),
-                    ptr(domain_flag).value if domain_flag is not None else None)
+    pj = None
+    if proj is not None:
+        pw, px, pH, pW, pbits = proj
+        pj = Projection(pw.handle.value, ptr(px).value, int(pH), int(pW), int(pbits))
+    e = Epilogue(ptr(bn_inv).value, ptr(bn_shift).value, fn, act_bits, pool, out_store,
+                 ptr(res).value, res_store, res_bits, float(post_scale), tc, ts,
+                 fold.handle.value if fold is not None else None,
+                 _default_flags if flags is None else int(flags),
+                 ptr(domain_flag).value if domain_flag is not None else None,
+                 ctypes.addressof(pj) if pj is not None else None)
+    e._proj = pj
+    return e
 
 
 class Fold:
@@ -428,10 +449,10 @@ def faithful_trick(klm, promotion="nep50"):
 
 def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NONE, act_bits=0,
            pool=1, out_store=STORE_F32, res=None, res_store=STORE_F32, res_bits=0, post_scale=1.0, out=None, trick=None,
-           fold=None, domain_flag=None):
+           fold=None, domain_flag=None, proj=None):
     """Run qnn_conv2d_forward; x is a float32 NHWC tensor, a uint8 NHWC tensor or an int32 packed tensor.
     Returns (y, Hp, Wp): y float32 (N,Hp,Wp,cout) or int32 (N*Hp*Wp, words); `out` = a tensor of that shape to write
-    into instead of a fresh one."""
+    into instead of a fresh one.  proj: see make_epilogue (raises QnnUnsupported where no kernel computes it)."""
     kh, kw, cin, cout = w.shape
     Ho = out_hw(H, kh, w.stride, w.same_pad) // pool
     Wo = out_hw(W, kw, w.stride, w.same_pad) // pool
@@ -446,9 +467,12 @@ def conv2d(w, x, x_store, x_bits, N, H, W, bn_inv=None, bn_shift=None, fn=FN_NON
             raise QnnError("conv2d: `out` must be a contiguous %s tensor of shape %s on %s" % (dt, shape, x.device))
         y = out
     epi = make_epilogue(bn_inv, bn_shift, fn, act_bits, pool, out_store, res, res_store, res_bits, post_scale, trick, fold,
-                        domain_flag)
-    check(load().qnn_conv2d_forward(w.handle, ptr(x), _first_store(x_store), x_bits, N, H, W, ctypes.byref(epi),
-                                    ptr(y), stream_ptr()), "qnn_conv2d_forward")
+                        domain_flag, proj=proj)
+    rc = load().qnn_conv2d_forward(w.handle, ptr(x), _first_store(x_store), x_bits, N, H, W, ctypes.byref(epi),
+                                   ptr(y), stream_ptr())
+    if proj is not None and rc == QNN_EUNSUPPORTED:
+        raise QnnUnsupported("qnn_conv2d_forward: " + load().qnn_last_error().decode(errors="replace"))
+    check(rc, "qnn_conv2d_forward")
     return y, Ho, Wo
 
 

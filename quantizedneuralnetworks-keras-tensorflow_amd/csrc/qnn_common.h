@@ -134,6 +134,12 @@ struct EpiArgs {
     int first_mode;            // domain declared for this call's float32 input: 0 none, 1 image bytes / 255, 2 [0, 1]
     uint32_t* dom_flag;        // the caller's domain-flag word for this call (qnn_epilogue_t.domain_flag) or nullptr = the handle's
     const float* fold_c;       // "bits" form of the fold (fold_b carries 0x4B400000, u = fma(as_float(acc), a, c)), or nullptr
+    // projection shortcut computed inside the launch (qnn_projection_t, qnn_abi.h), or proj_x == nullptr
+    const uint8_t* proj_x;     // block input: N x proj_H x proj_W x proj_cin int4 codes
+    const uint8_t* proj_w;     // [cout][proj_cin] bytes code * 16 (the 1x1 kernel's d_mfma image)
+    const float* proj_bias;    // or nullptr
+    float proj_scale;          // 2^-(wshift + x_bits - 1) of the projection
+    int proj_cin, proj_H, proj_W;
 };
 
 #ifdef __HIPCC__

@@ -1133,7 +1133,7 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
     e->res_store = epi->res_store;
     e->res_cw = 0;
     e->res_scale = 1.0f;
-    e->post_scale = epi->res ? epi->post_scale : 1.0f;
+    e->post_scale = (epi->res || epi->proj) ? epi->post_scale : 1.0f;
     e->trick_c = epi->trick_s != 0.0f ? epi->trick_c : 0.0f;
     e->trick_s = epi->trick_s;
     e->fold_a = nullptr;
@@ -1142,6 +1142,27 @@ int check_epilogue(const qnn_weights* w, const qnn_epilogue_t* epi, int xshift, 
     e->dom_flag = epi->domain_flag;
     e->flags = epi->flags;
     e->first_mode = 0;
+    e->proj_x = nullptr; e->proj_w = nullptr; e->proj_bias = nullptr;
+    e->proj_scale = 1.0f; e->proj_cin = 0; e->proj_H = 0; e->proj_W = 0;
+    if (epi->proj) {
+        // the shortcut as a 1x1 strides-2 convolution of the block input, computed inside the launch (qnn_projection_t)
+        const qnn_projection_t* pj = epi->proj;
+        QNN_REQUIRE(pj->w && pj->x, QNN_EINVAL, "epilogue: proj needs the 1x1 weights and the block input");
+        QNN_REQUIRE(!epi->res && !epi->fold && epi->trick_s == 0.0f && epi->pool == 1, QNN_EINVAL,
+                    "epilogue: proj excludes res, fold, the identity trick and pooling");
+        const qnn_weights* pw = pj->w;
+        QNN_REQUIRE(pw->kh == 1 && pw->kw == 1 && pw->stride == 2 && pw->store == QNN_STORE_I4 && pw->cout == w->cout,
+                    QNN_EINVAL, "epilogue: proj weights must be a 1x1 strides-2 int4 kernel with the layer's cout");
+        QNN_REQUIRE(pj->x_bits >= 1 && pj->x_bits <= 4 && pj->H > 0 && pj->W > 0, QNN_EINVAL,
+                    "epilogue: proj x_bits=%d, H=%d, W=%d", pj->x_bits, pj->H, pj->W);
+        QNN_REQUIRE(pw->d_mfma != nullptr, QNN_EUNSUPPORTED,
+                    "epilogue: proj with %d -> %d channels is not supported (keep the two-launch form)", pw->cin, pw->cout);
+        e->proj_x = (const uint8_t*)pj->x;
+        e->proj_w = pw->d_mfma;
+        e->proj_bias = pw->d_bias;
+        e->proj_scale = ldexpf(1.0f, -(pw->wshift + pj->x_bits - 1));
+        e->proj_cin = pw->cin; e->proj_H = pj->H; e->proj_W = pj->W;
+    }
     if (epi->fold) {
         // the fold must have been prepared for exactly this layer and epilogue; a handle whose sweep found a differing
         // point on some channel (folded < cout) is accepted and ignored: the kernels evaluate the float32 chain
@@ -1279,6 +1300,15 @@ int conv_forward(const qnn_weights* w, const void* x, int x_store, int x_bits, i
     QNN_REQUIRE(!(trick && dense), QNN_EINVAL, "dense_forward: the reference's Dense layers have no identity trick");
     const int pref = trick ? 1 : qnn_conv_impl_pref();
     bool launched = false;
+    if (e.proj_x) {
+        // the in-launch projection shortcut: the row-walking strip kernel or nothing (the caller keeps two launches)
+        const bool ok = !dense && qnn_try_launch_mfma(g, e, x_store, x, w, y, s, name, sizeof(name)) == 0;
+        QNN_REQUIRE(ok, QNN_EUNSUPPORTED, "conv_forward: no kernel computes a projection shortcut for this layer "
+                    "(3x3 stride-1 int4, cin = cout in {32, 64}, proj cin = cin / 2, output ceil(H/2) x ceil(W/2) of the block input)");
+        qnn_set_kernel_name(name);
+        QNN_HIP(hipGetLastError());
+        return QNN_OK;
+    }
     if (dense && !e.res && x_store != QNN_STORE_F32 && e.out_store == QNN_STORE_F32 && (w->kwords % 4) == 0) {
         int rc2 = x_store == QNN_STORE_BIN  ? launch_dense<QNN_STORE_BIN>(x, w, e, y, N, s)
                   : x_store == QNN_STORE_T2 ? launch_dense<QNN_STORE_T2>(x, w, e, y, N, s)

@@ -754,7 +754,12 @@ int qnn_mfma_prepare_weights(qnn_weights* w, hipStream_t s) {
     w->d_mfma = nullptr;
     const bool small = w->store == QNN_STORE_I4 && (w->cin == 16 || w->cin == 32) && (w->cout % 16) == 0 &&
                        w->kh == 3 && w->kw == 3;
-    if (!small && (w->cin % 64 != 0 || w->cout % 64 != 0)) return QNN_OK;
+    // the 1x1 strides-2 projection of a ResNet stage (models/resnet.py:117-124): read by the strip kernel of the block's
+    // second convolution when the shortcut is computed inside that launch (qnn_projection_t); no kernel of this file
+    // runs such a layer on its own
+    const bool proj = w->store == QNN_STORE_I4 && (w->cin == 16 || w->cin == 32) && w->cout == 2 * w->cin &&
+                      w->kh == 1 && w->kw == 1 && w->stride == 2;
+    if (!small && !proj && (w->cin % 64 != 0 || w->cout % 64 != 0)) return QNN_OK;
     if (w->store == QNN_STORE_I8) {
         w->d_mfma = (uint8_t*)w->d_packed;      // int8 codes, natural channel order
         return QNN_OK;
@@ -808,13 +813,15 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
     // activation's code scale.
     {
         int pexp = 0;
-        const bool pow2 = !e.res || (e.post_scale > 0.0f && frexpf(e.post_scale, &pexp) == 0.5f);
+        const bool pow2 = (!e.res && !e.proj_x) || (e.post_scale > 0.0f && frexpf(e.post_scale, &pexp) == 0.5f);
         const int cmul = g.cin == 16 ? 16 : 32;
         // stride 2 (the first conv of a stage: no residual, Cin 16 / 32, Cout a multiple of 32): the same walk over
         // output rows, three fresh input rows per output row
         const bool s1 = g.stride == 1 && g.pt == 1 && g.pl == 1 && (g.cout % cmul) == 0;
         const bool s2 = g.stride == 2 && (g.cin == 16 || g.cin == 32) && (g.cout % 32) == 0 && !e.res;
-        const bool shape = x_store == QNN_STORE_I4 && w->store == QNN_STORE_I4 &&
+        const bool proj_ok = !e.proj_x || (s1 && (g.cin == 32 || g.cin == 64) && g.cout == g.cin && e.proj_cin * 2 == g.cin &&
+                                           !e.res && !e.fold_a && (e.proj_H + 1) / 2 == g.H && (e.proj_W + 1) / 2 == g.W);
+        const bool shape = x_store == QNN_STORE_I4 && w->store == QNN_STORE_I4 && proj_ok &&
                            (g.cin == 16 || g.cin == 32 || g.cin == 64) && g.kh == 3 && g.kw == 3 && (s1 || s2) &&
                            g.pool == 1 && e.out_store == QNN_STORE_I4 && pow2 &&
                            (!e.res || (e.res_store == QNN_STORE_I4 && e.res_cw == e.ocw) ||
@@ -832,6 +839,7 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                 ms.x_bytes = 0; ms.w_bytes = (uint32_t)wb_; ms.ablate = 0;
                 EpiArgs es = e;
                 es.scale = e.scale * (1.0f / 256.0f);        // both operands carry *16
+                es.proj_scale = e.proj_scale * (1.0f / 256.0f);
                 // 16 -> 16 channels with a usable fold and an even width: the LDS-staged form (qnn_mfma_strip16.hip: a sixth
                 // of the load and a quarter of the store instructions)
                 static const bool lds16_off = QNN_ENV_STR("QNN_STRIP16_LDS_OFF") != nullptr;   // A/B switch (experiment builds only)
@@ -839,12 +847,13 @@ int qnn_try_launch_mfma(const ConvGeom& g, const EpiArgs& e, int x_store, const 
                     snprintf(name, name_len, "strip_i4_c16_lds");
                     return 0;
                 }
-                snprintf(name, name_len, g.stride == 2 ? "strip_i4_c%d_s2" : "strip_i4_c%d", g.cin);
+                snprintf(name, name_len, g.stride == 2 ? "strip_i4_c%d_s2" : e.proj_x ? "strip_i4_c%d_proj" : "strip_i4_c%d", g.cin);
                 if (qnn_launch_strip(g.cin, ms, es, x, w->d_mfma, y, s) == 0) return 0;
             }
         }
     }
     // small-channel 3x3 int4 layers on the tile kernel (both operands in registers)
+    if (e.proj_x) return 1;      // the in-launch projection shortcut exists in the strip kernel only
     if (x_store == QNN_STORE_I4 && w->store == QNN_STORE_I4 && (g.cin == 16 || g.cin == 32) && g.kh == 3 &&
         g.kw == 3 && g.stride == 1 && g.pt == 1 && g.pl == 1 && g.pool == 1 && (g.W % 16) == 0 &&
         e.out_store == QNN_STORE_I4 && (g.cout % (g.cin == 16 ? 16 : 32)) == 0 &&

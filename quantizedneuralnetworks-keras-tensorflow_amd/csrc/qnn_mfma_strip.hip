@@ -80,7 +80,10 @@ __device__ __forceinline__ void strip_block_map(int& xw, int& yblk) {
 // cvt + mul, per pair one v_cvt_pknorm_i16_f32 (+ two v_pk_add_i16 clamp with a shortcut), and the nibbles of a lane's
 // field are gathered with two v_perm_b32 + shift + v_bfi_b32 (NT = 2) instead of cvt, [add], mul, add, [bfe, cvt, fma],
 // add, v_med3 and a shift-or per value.
-template <int CIN, int NT, int RES, bool BIAS, int FOLD>   // RES: 0 none, 1 packed int4 shortcut, 2 float32 shortcut; FOLD: 0 chain, 1 / 2 = fold modes (qnn_fold.h)
+// RES: 0 none, 1 packed int4 shortcut, 2 float32 shortcut, 3 projection shortcut computed here (qnn_projection_t: the
+// 1x1 strides-2 convolution of the block input with CIN / 2 channels, one more MFMA per tile and row on the even pixels of
+// the even input rows -- the float32 tensor RES = 2 reads is never formed); FOLD: 0 chain, 1 / 2 = fold modes (qnn_fold.h)
+template <int CIN, int NT, int RES, bool BIAS, int FOLD>
 __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RES == 2 ? 2 : QNN_STRIP32_WPS) : QNN_STRIP64_WPS)) void k_conv_strip(MfmaGeom mg, EpiArgs e,
                                                                  const uint8_t* __restrict__ x,
                                                                  const uint8_t* __restrict__ wq8,
@@ -147,7 +150,29 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
         }
     const v2f rcoef2 = {rcoef, rcoef};
     // folded epilogue: per-channel slope and accumulator offset (the MFMA chain starts from the offset)
-    static_assert(!FOLD || RES != 2, "the float32 shortcut is not folded");
+    static_assert(!FOLD || RES < 2, "the float32 shortcuts are not folded");
+    static_assert(RES != 3 || (NT == 2 && CIN >= 32), "projection shortcut: 32 / 64 channel stages");
+    // ---- projection shortcut (RES = 3): 1x1 filters as one more A operand per tile; K-blocks beyond CIN / 2 channels are
+    // out of range = zeros, and so are the same lanes' pixel loads ----
+    constexpr int P0B = CIN / 4;                      // bytes per stored pixel of the block input (CIN / 2 channels)
+    constexpr int BPP = CIN / 32;                     // its 16-channel k-blocks: 1 / 2
+    v4i bwp[NT];
+    v2f pbias[NT][2];
+    const v2f pscale2 = {e.proj_scale, e.proj_scale};
+    if constexpr (RES == 3) {
+        const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(e.proj_w), 0, g.cout * (CIN / 2), 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ch = nbase + 4 * NT * (r >> 2) + 4 * nt + (r & 3);
+            const int woff = kq < BPP ? ch * (CIN / 2) + kq * 16 : (int)0x80000000;
+            bwp[nt] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(prsrc, woff, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                pbias[nt][i >> 1][i & 1] = e.proj_bias ? e.proj_bias[nbase + 4 * NT * kq + 4 * nt + i] : 0.0f;
+        }
+    }
+    const bool has_pbias = e.proj_bias != nullptr;
     float fa[NT][4], fc[NT][4];
     v4i binit[NT];
 #pragma unroll
@@ -168,7 +193,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
     const int code_lo = kMagicBits - (int)e.act_m, code_hi = kMagicBits + (int)e.act_m - 1;
     const int rowb = g.W * PIXB;                      // bytes per input row
     const int orowb = g.W * e.ocw * 4;                // bytes per output row
-    const int rrowb = RES == 2 ? g.W * g.cout * 4 : orowb;
+    const int rrowb = RES == 2 ? g.W * g.cout * 4 : RES == 3 ? 2 * e.proj_W * P0B : orowb;   // (RES = 3: every other input row)
 
     auto widen = [&](const uint2& q) -> v4i {
         const uint4 v = make_uint4((q.x << 4) & 0xF0F0F0F0u, q.x & 0xF0F0F0F0u,
@@ -189,7 +214,8 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
             (uint8_t*)y + (size_t)n * img_y, 0, (int)img_y, 0x00020000);
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-            RES != 0 ? (uint8_t*)const_cast<void*>(e.res) + (size_t)n * img_r : (uint8_t*)y, 0,
+            RES == 3 ? const_cast<uint8_t*>(e.proj_x) + (size_t)n * img_r
+                     : RES != 0 ? (uint8_t*)const_cast<void*>(e.res) + (size_t)n * img_r : (uint8_t*)y, 0,
             RES != 0 ? (int)img_r : 0, 0x00020000);
         // byte offset (inside the image) of this lane's k-block in input row y0 - 1; lanes whose pixel lies left or right of
         // the image start out of range and stay there (0x80000000 + row increments < 2^32)
@@ -202,6 +228,7 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
         const bool pvalid = xs + r < g.W;                                       // last strip of a ragged row
         int ovoff = pvalid ? (y0 * g.W + xs + r) * e.ocw * 4 + nbase / 2 + kq * 2 * NT : (int)0x80000000;   // 2*NT bytes
         int rvoff = RES == 2 ? (pvalid ? ((y0 * g.W + xs + r) * g.cout + nbase + 4 * NT * kq) * 4 : (int)0x80000000)
+                    : RES == 3 ? ((pvalid && kq < BPP) ? (2 * y0 * e.proj_W + 2 * (xs + r)) * P0B + kq * 8 : (int)0x80000000)
                              : ovoff;                                           // + nt*16 (f32: the next four floats)
 
         // Loads are requested D rows ahead (a ring of D raw input-row register sets and D shortcut registers): vmcnt retires
@@ -232,6 +259,10 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
             if constexpr (RES == 1) {
                 if constexpr (NT == 1) ds[0] = __builtin_amdgcn_raw_buffer_load_b16(rr, rvoff, 0, 0);
                 else ds[0] = __builtin_amdgcn_raw_buffer_load_b32(rr, rvoff, 0, 0);        // both tiles' codes in one word
+            }
+            if constexpr (RES == 3) {                  // this lane's k-block of block-input pixel (2 yy, 2 (xs + r)): 16 codes
+                const uint2 t = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rr, rvoff, 0, 0));
+                ds[0] = t.x; ds[NT - 1] = t.y;
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -268,6 +299,13 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { rcur[nt] = rsc[nt]; fcur[nt] = rfc[nt]; }
             if constexpr (RES != 0) load_res(rsc, rfc);   // shortcut of row yy + D
+            v4i accp[NT];
+            if constexpr (RES == 3) {
+                const v4i Xp = widen(make_uint2(rcur[0], rcur[NT - 1]));
+                const v4i z0 = {0, 0, 0, 0};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) accp[nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bwp[nt], Xp, z0, 0, 0, 0);
+            }
             v4i acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -347,6 +385,12 @@ __global__ __launch_bounds__(256, (CIN == 16 ? QNN_STRIP16_WPS : CIN == 32 ? (RE
                     if constexpr (RES == 2) {
                         const v2f rv = h == 0 ? v2f{fcur[nt].x, fcur[nt].y} : v2f{fcur[nt].z, fcur[nt].w};
                         u = __builtin_elementwise_fma(rv, rcoef2, u);   // (x + y) * 2^k == x*2^k + y*2^k, one rounding either way
+                    }
+                    if constexpr (RES == 3) {
+                        // the float32 value k_conv_pw_f32 stores for this shortcut: float(sum) * scale [+ bias], one rounding each
+                        v2f rv = v2f{(float)accp[nt][2 * h], (float)accp[nt][2 * h + 1]} * pscale2;
+                        if (has_pbias) rv = rv + pbias[nt][h];
+                        u = __builtin_elementwise_fma(rv, rcoef2, u);
                     }
                     u2[h] = u;
                 }
@@ -634,8 +678,10 @@ int launch_strip(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     const int spr = (g.W + 15) / 16;
     const int ny = g.cout / (16 * NT);
     const double img_x = (double)g.H * g.W * (CIN / 2), img_y = (double)g.H * g.W * e.ocw * 4.0;
-    const int res = !e.res ? 0 : e.res_store == QNN_STORE_F32 ? 2 : 1;
-    const double img_r = res == 2 ? (double)g.H * g.W * g.cout * 4.0 : img_y;
+    const int res = e.proj_x ? 3 : !e.res ? 0 : e.res_store == QNN_STORE_F32 ? 2 : 1;
+    const double img_r = res == 2 ? (double)g.H * g.W * g.cout * 4.0
+                         : res == 3 ? (double)e.proj_H * e.proj_W * (CIN / 4) : img_y;
+    if (res == 3 && (NT != 2 || CIN < 32 || e.proj_cin * 2 != CIN)) return 1;
     if (img_x >= 1.0e9 || img_y >= 1.0e9 || img_r >= 1.0e9 || ny < 1 || ny * 16 * NT != g.cout) return 1;
     // persistent grid: WPS waves per SIMD; rows per task chosen so that the task count fills whole
     // rounds of that grid (a round costs rc output rows + 3 rows of pipeline fill)
@@ -657,7 +703,7 @@ int launch_strip(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
     long blocks = (ntasks + 3) / 4;
     if (blocks > blocks_cap) blocks = blocks_cap;
     const dim3 grid((unsigned)blocks, (unsigned)ny), block(256);
-    const bool bias = e.bias != nullptr && !(e.fold_a != nullptr && res != 2);   // a fold contains the bias
+    const bool bias = e.bias != nullptr && !(e.fold_a != nullptr && res < 2);   // a fold contains the bias
 #define STRIP_CASE(RES_, BIAS_, FOLD_)                                                                        \
     if (res == RES_ && bias == BIAS_ && fold == FOLD_) {                                                      \
         hipLaunchKernelGGL((k_conv_strip<CIN, NT, RES_, BIAS_, FOLD_>), grid, block, 0, s, mg, e, (const uint8_t*)x, w, y, \
@@ -666,10 +712,11 @@ int launch_strip(const MfmaGeom& mg, const EpiArgs& e, const void* x, const uint
         return 0;                                                                                             \
     }
     // folded epilogue: everything behind the accumulator (bias included) is inside the fold's two constants
-    const int fold = (e.fold_a == nullptr || res == 2) ? 0 : e.fold_c ? 2 : 1;
+    const int fold = (e.fold_a == nullptr || res >= 2) ? 0 : e.fold_c ? 2 : 1;
     STRIP_CASE(0, false, 2) STRIP_CASE(1, false, 2) STRIP_CASE(0, false, 1) STRIP_CASE(1, false, 1)
     STRIP_CASE(0, false, 0) STRIP_CASE(0, true, 0) STRIP_CASE(1, false, 0) STRIP_CASE(1, true, 0)
     STRIP_CASE(2, false, 0) STRIP_CASE(2, true, 0)
+    if constexpr (NT == 2 && CIN >= 32) { STRIP_CASE(3, false, 0) STRIP_CASE(3, true, 0) }
 #undef STRIP_CASE
     return 1;
 }

@@ -635,7 +635,7 @@ class ResidualFusedModel:
     float32 torch ops on unpacked tensors.
     """
 
-    def __init__(self, spec, device="cuda", first_layer="auto", fold=True):
+    def __init__(self, spec, device="cuda", first_layer="auto", fold=True, fuse_projection=True):
         """first_layer: kernel for float32 images in front of the first (3-channel) conv, as engine.FusedModel:
         "auto" (default: byte kernel with a per-batch domain flag, a batch that is not bytes / 255 is recomputed on the
         exact kernel), "exact" or "image" (float32 bytes / 255 recognised as bytes; domain flag -> check_domain()).  uint8
@@ -650,6 +650,8 @@ class ResidualFusedModel:
         self._exact_now = False
         self.fold = bool(fold)
         self._folds = {}                     # (conv, bn, shortcut kind, ...) -> _abi.Fold or None
+        self.fuse_projection = bool(fuse_projection)   # projection shortcuts inside the second conv's launch (qnn_projection_t)
+        self._proj_ok = {}                   # conv index -> the pair is eligible (False after a QNN_EUNSUPPORTED)
         self.device = torch.device(device)
         self.spec = spec
         self.names = [op.get("dst", "t%d" % i) for i, op in enumerate(spec)]
@@ -691,6 +693,26 @@ class ResidualFusedModel:
         if i is None or self.spec[i]["op"] != kind or len(self.cons.get(name, [])) != 1:
             return None
         return i
+
+    def _projection_of(self, short, ci, fn, bits, out_store):
+        """Index of the conv op behind shortcut `short` if it is a projection the second conv `ci` of the block can compute
+        inside its own launch (qnn_projection_t, include/qnn_abi.h): a 1x1 strides-2 4-bit QuantizedConv2D with one consumer
+        (models/resnet.py:117-124), `ci` a 3x3 stride-1 4-bit layer with cin = cout in {32, 64} = twice the projection's
+        input channels, packed 4-bit quantized_tanh output.  None = keep the float32 shortcut tensor."""
+        if not self.fuse_projection or self._proj_ok.get(ci) is False:
+            return None
+        pi = self._single(short, "conv")
+        if pi is None:
+            return None
+        po, mo = self.spec[pi], self.spec[ci]
+        pk, mk = po["kernel"].shape, mo["kernel"].shape
+        ok = (po.get("kind") == "quantized" and po.get("nb") == 4 and mo.get("kind") == "quantized" and mo.get("nb") == 4
+              and tuple(pk[:2]) == (1, 1) and tuple(po.get("strides", (1, 1))) == (2, 2)
+              and tuple(mk[:2]) == (3, 3) and tuple(mo.get("strides", (1, 1))) == (1, 1) and mo.get("padding", "same") == "same"
+              and mk[2] == mk[3] and mk[3] in (32, 64) and pk[3] == mk[3] and 2 * pk[2] == mk[2]
+              and fn == _abi.FN_QUANTIZED_TANH and bits == 4 and out_store == _abi.STORE_I4)
+        self._proj_ok[ci] = bool(ok)
+        return pi if ok else None
 
     def _act_out_store(self, name, bits):
         """Packed store the consumers of activation `name` want, or None if one needs float32."""
@@ -773,12 +795,17 @@ class ResidualFusedModel:
             v = ev(name)
             return v.to_f32() if isinstance(v, _Packed) else v
 
-        def conv_call(ci, bn_i, res, post_scale, fn, bits, out_store):
-            """Launch conv `ci` with everything fused behind it."""
+        def conv_call(ci, bn_i, res, post_scale, fn, bits, out_store, proj=None):
+            """Launch conv `ci` with everything fused behind it.  proj = (conv index of a 1x1 strides-2 projection, its packed
+            input): the shortcut is computed inside this launch (qnn_projection_t) instead of being read from `res`."""
             op = self.spec[ci]
             src = ev(self.srcs[ci][0])
             inv, shift = self._bn[bn_i] if bn_i is not None else (None, None)
             rkw = {}
+            if proj is not None:
+                psrc = proj[1]
+                rkw = dict(post_scale=post_scale,
+                           proj=(self._weights(proj[0], psrc.store), psrc.t, psrc.shape[1], psrc.shape[2], psrc.bits))
             if res is not None:
                 if isinstance(res, _Packed) and res.store == _abi.STORE_T2:
                     res = res.to_f32()           # the shortcut operand of the epilogue reads codes or float32, not bit planes
@@ -809,7 +836,8 @@ class ResidualFusedModel:
                     dflag = self._own_flag()
 
             fold = None
-            if self.fold and xs == _abi.STORE_I4 and out_store == _abi.STORE_I4 and fn == _abi.FN_QUANTIZED_TANH and ab == 4 \
+            if self.fold and proj is None and xs == _abi.STORE_I4 and out_store == _abi.STORE_I4 \
+                    and fn == _abi.FN_QUANTIZED_TANH and ab == 4 \
                     and (res is None or (isinstance(res, _Packed) and res.store == _abi.STORE_I4 and res.bits == 4)):
                 fkey = (ci, bn_i, xb, None if res is None else float(post_scale))
                 if fkey not in self._folds and not torch.cuda.is_current_stream_capturing():
@@ -838,9 +866,13 @@ class ResidualFusedModel:
                 b = nbytes(xs, N * H * W, C) + nbytes(out_store, N * Ho * Wo, cout)
                 if res is not None:
                     b += nbytes(rkw["res_store"], N * Ho * Wo, cout)
+                if proj is not None:                 # the even rows of the block input (every other pixel of a row shares its
+                    ps = proj[1].shape               # 32-byte sectors with the pixels that are read)
+                    b += nbytes(proj[1].store, ps[0] * ((ps[1] + 1) // 2) * ps[2], ps[3])
                 self.capture.append(dict(kernel=_abi.last_kernel(), launch=lambda: launch()[0],
                                          shape=(N, H, W, C, cout, kh, tuple(op.get("strides", (1, 1)))[0],
-                                                "res_" + ("none" if res is None else "packed" if isinstance(res, _Packed) else "f32")),
+                                                "res_" + ("proj" if proj is not None else "none" if res is None
+                                                          else "packed" if isinstance(res, _Packed) else "f32")),
                                          bytes=b, macs=N * Ho * Wo * kh * kw * C * cout,
                                          pipe="f32" if _abi.last_kernel().startswith("mfma_f32") else "i8"))
             if out_store == _abi.STORE_F32:
@@ -889,6 +921,15 @@ class ResidualFusedModel:
                             for main, short in ((b_n, a_n), (a_n, b_n)):
                                 cb = conv_bn_of(main)
                                 if cb is not None and _ok_lowbit(self.spec[cb[0]]):
+                                    pj = self._projection_of(short, cb[0], fn, bits, out_store)
+                                    if pj is not None:
+                                        psrc = ev(self.srcs[pj][0])
+                                        if isinstance(psrc, _Packed) and psrc.store == _abi.STORE_I4:
+                                            try:
+                                                out = conv_call(cb[0], cb[1], None, post, fn, bits, out_store, proj=(pj, psrc))
+                                                break
+                                            except _abi.QnnUnsupported:      # no kernel for this pair: two launches, as before
+                                                self._proj_ok[cb[0]] = False
                                     res = ev(short)
                                     out = conv_call(cb[0], cb[1], res, post, fn, bits, out_store)
                                     break

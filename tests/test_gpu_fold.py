@@ -103,7 +103,9 @@ def _packed_codes(rng, n, h, w_, c):
                                                   (64, 64, (14, 14), 3, 1), (64, 128, (5, 23), 2, 1), (16, 32, (16, 16), 2, 2),
                                                   (32, 64, (7, 9), 2, 2), (16, 16, (224, 224), 1, 1), (16, 16, (1, 2), 2, 1),
                                                   (16, 16, (3, 18), 3, 1), (16, 16, (13, 50), 70, 1), (16, 16, (40, 16), 2, 1),
-                                                  (16, 16, (25, 34), 400, 1)])
+                                                  (16, 16, (25, 34), 400, 1), (32, 32, (112, 112), 2, 1), (64, 64, (56, 56), 2, 1),
+                                                  (32, 32, (1, 1), 3, 1), (64, 64, (3, 17), 5, 1), (32, 32, (26, 33), 40, 1),
+                                                  (64, 64, (13, 16), 300, 1)])
 @pytest.mark.parametrize("gamma_sign", [None, 1.0, -1.0])
 def test_strip_kernels_with_and_without_the_fold(cin, cout, hw, n, stride, gamma_sign):
     """k_conv_strip / k_conv_strip_s2 with the folded epilogue: the same bits as the float32 chain and as the oracle, with

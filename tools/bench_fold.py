@@ -32,7 +32,8 @@ for (n, hw, cin, cout, stride) in SHAPES:
         f = _abi.Fold.try_prepare(w, _abi.STORE_I4, 4, inv, shift, _abi.FN_QUANTIZED_TANH, 4, _abi.STORE_I4, **kw)
         row = dict(shape=[n, hw, cin, cout, stride], res=res, folded=[f.folded, f.channels] if f else None)
         ref = None
-        for name, fold in (("chain", None), ("fold", f)):
+        for name, fold, lds in (("chain", None, 1), ("fold", f, 1), ("fold_nolds", f, 0)):
+            _abi.set_option("lds16", lds)            # 0: the register-staged strip kernel with the same folded epilogue
             def launch():
                 _abi.conv2d(w, x, _abi.STORE_I4, 4, n, hw, hw, inv, shift, _abi.FN_QUANTIZED_TANH, 4, 1, _abi.STORE_I4,
                             out=y, fold=fold, **kw)
@@ -47,11 +48,12 @@ for (n, hw, cin, cout, stride) in SHAPES:
             g.replay(); torch.cuda.synchronize()
             e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
             row[name + "_us"] = round(e0.elapsed_time(e1) * 1e3 / reps, 2)
-            row["kernel"] = _abi.last_kernel()
+            row[name + "_kernel"] = _abi.last_kernel()
             got = y.clone()
             if ref is None:
                 ref = got
             else:
-                row["same_bits"] = bool(torch.equal(ref, got))
+                row["same_bits"] = row.get("same_bits", True) and bool(torch.equal(ref, got))
+        _abi.set_option("lds16", 1)
         out.append(row)
         print(json.dumps(row), flush=True)

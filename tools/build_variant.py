@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B kernel experiments: build csrc/variants/libqnn_<name>.so that differs from the in-tree library only in
-the extra compiler flags given for ONE translation unit.  Select it at run time with QNN_LIB=<path>.
+the extra compiler flags given for ONE translation unit (or several: a comma-separated list).  Select it at run time with
+QNN_LIB=<path>.
     python tools/build_variant.py wps2 qnn_first.hip -DQNN_FIRST_WPS=2
+    python tools/build_variant.py exp qnn_first_u8.hip,qnn_mfma_areg.hip -DQNN_EXPERIMENTS
 Variants are build artefacts (git-ignored); they travel to the GPU box with gpurun like the main library."""
 import importlib
 import os
@@ -18,10 +20,12 @@ def main():
     b.build()                                      # the other objects come from the regular build
     vdir = os.path.join(b.CSRC, "variants")
     os.makedirs(vdir, exist_ok=True)
-    obj = os.path.join(vdir, "%s_%s.o" % (tu[:-4], name))
-    subprocess.run([b._hipcc()] + b.CFLAGS + flags + ["-c", os.path.join(b.CSRC, tu), "-o", obj], check=True)
-    objs = [obj if os.path.basename(s) == tu else os.path.join(b.OBJDIR, os.path.basename(s)[:-4] + ".o")
-            for s in b._sources()]
+    tus = tu.split(",")
+    built = {}
+    for t in tus:
+        built[t] = os.path.join(vdir, "%s_%s.o" % (t[:-4], name))
+        subprocess.run([b._hipcc()] + b.CFLAGS + flags + ["-c", os.path.join(b.CSRC, t), "-o", built[t]], check=True)
+    objs = [built.get(os.path.basename(s), os.path.join(b.OBJDIR, os.path.basename(s)[:-4] + ".o")) for s in b._sources()]
     lib = os.path.join(vdir, "libqnn_%s.so" % name)
     subprocess.run([b._hipcc()] + b.LDFLAGS + ["-o", lib] + objs, check=True)
     print(lib)
