@@ -64,6 +64,7 @@ TAG_PATTERNS = [
     (r"^strip_i4_c(\d+):res_none$", r"^k_conv_strip<\1, \d, 0,"),
     (r"^strip_i4_c(\d+):res_packed$", r"^k_conv_strip<\1, \d, 1,"),
     (r"^strip_i4_c(\d+):res_f32$", r"^k_conv_strip<\1, \d, 2,"),
+    (r"^strip_i4_c(\d+)_proj(:res_\w+)?$", r"^k_conv_strip<\1, \d, 3,"),
     (r"^strip_i4_c(\d+)$", r"^k_conv_strip<\1,"),
     (r"^mfma_i(\d)_(\d+)x(\d+)$", None),          # tile sizes -> waves, handled below
     (r"^dense_i(\d)$", r"^k_dense_packed(_split)?<\1,"),
