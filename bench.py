@@ -832,8 +832,12 @@ def main_rank(args):
                 nb = 64 if N * cf.dim * cf.dim * cf.channels * 4 * 64 < 8e9 else 8
                 xb = torch.cat([torch.as_tensor(make_input(args.first_layer, N, nets.SEED_BASE + idx + 31 * b)) for b in range(8)]
                                ).cuda().repeat(nb // 8, 1, 1, 1)
-                for _ in range(3):
+                # warm-up: the GPU has idled while the 3.2 GB of images were built on the host; its clocks need a few
+                # hundred ms of load to come back (tools/predict_breakdown.py: the first ~30 ms of calls run 7 % slower)
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < 0.5:
                     mp.predict(xb, batch_size=N)
+                    torch.cuda.synchronize()
                 ts = []
                 for _ in range(9):
                     torch.cuda.synchronize()

@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kCandidates = 33;      // slope candidates: the rounded real-number slope and +-1 .. +-16 float32 neighbours
+constexpr int kCandidates = 129;     // slope candidates: the rounded real-number slope and +-1 .. +-64 float32 neighbours
 
 struct FoldProblem {
     EpiArgs e;                       // chain constants; e.scale = 2^-(wshift + xshift), e.res unused

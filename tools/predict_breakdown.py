@@ -65,5 +65,23 @@ for _ in range(7):
             ln["graphs"][(i // len(gl)) % 8].replay()
     torch.cuda.synchronize(); gs.append(time.perf_counter() - t0)
 rows["graph_loop_ms"] = round(1e3 * float(np.median(gs)), 3)
+# fixed cost vs cost per batch: the same loops over 32 / 64 / 128 batches (wrapping around the resident tensor)
+for name in ("bound", "graph"):
+    for n_ in (32, 64, 128):
+        gs = []
+        for _ in range(7):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(n_):
+                if name == "bound":
+                    ln = bound[i % len(bound)]
+                    ln["plan"](ln["stream"].cuda_stream, xp + (i % nb) * xs, yp + (i % nb) * ys, fp + 4 * (i % nb))
+                else:
+                    ln = gl[i % len(gl)]
+                    with torch.cuda.stream(ln["stream"]):
+                        ln["graphs"][(i // len(gl)) % 8].replay()
+            torch.cuda.synchronize(); gs.append(time.perf_counter() - t0)
+        rows["%s_%d_ms" % (name, n_)] = round(1e3 * float(np.median(gs)), 3)
+    rows[name + "_us_per_batch"] = round((rows[name + "_128_ms"] - rows[name + "_32_ms"]) / 96 * 1e3, 2)
+    rows[name + "_fixed_us"] = round(rows[name + "_32_ms"] * 1e3 - 32 * rows[name + "_us_per_batch"], 1)
 rows["lanes"] = lanes
 print(json.dumps(rows))
