@@ -32,6 +32,42 @@ def test_library_exports_every_declared_symbol():
     assert _abi.load().qnn_version() == 4
 
 
+def test_ctypes_structures_match_the_header_layout(tmp_path):
+    """The structs a binding passes by pointer (qnn_epilogue_t, qnn_projection_t, qnn_fold_info_t): size and every field offset
+    of the ctypes mirrors in _abi.py against what the C compiler makes of include/qnn_abi.h."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    mirrors = {"qnn_epilogue_t": _abi.Epilogue, "qnn_projection_t": _abi.Projection, "qnn_fold_info_t": _abi.FoldInfo}
+    lines = []
+    for cname, cls in mirrors.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src = tmp_path / "layout.c"
+    src.write_text("#include <stdio.h>\n#include <stddef.h>\n#include \"qnn_abi.h\"\nint main(void) {\n%s\nreturn 0; }\n"
+                   % "\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {}
+    for ln in filter(None, out):
+        a, b, c = ln.split()
+        got[(a, b)] = int(c)
+    for cname, cls in mirrors.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+    # every field of the C structs is mirrored (a field added to the header only would shift nothing but be missing here)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "qnn_abi.h")).read(), flags=re.S)
+    for cname, cls in mirrors.items():
+        body = re.search(r"typedef struct \w+ \{([^{}]*)\} %s;" % cname, hdr).group(1)
+        nfields = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
+        assert nfields == len(cls._fields_), (cname, nfields, len(cls._fields_))
+
+
 def test_no_cpu_fallback():
     x = torch.zeros(4, 4)
     with pytest.raises(_abi.QnnError):
