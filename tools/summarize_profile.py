@@ -48,8 +48,8 @@ TAG_PATTERNS = [
     (r"^mfma_f32_first_cin(\d)$", r"^k_conv_first_(lds|mfma)<\1,"),
     (r"^mfma_f32_stem_cin(\d)$", r"^k_conv_stem<\1,"),
     (r"^pw_i4_f32$", r"^k_conv_pw_f32<"),
-    (r"^mfma_i4_halo64x64\+dense$", r"^k_conv_mfma_halo<\d+, \d+, (true|1)>"),
-    (r"^mfma_i4_halo64x64$", r"^k_conv_mfma_halo<\d+, \d+, (false|0)>"),
+    (r"^mfma_i4_halo64x64\+dense$", r"^k_conv_mfma_halo<\d+, \d+, (true|1)[,>]"),
+    (r"^mfma_i4_halo64x64$", r"^k_conv_mfma_halo<\d+, \d+, (false|0)[,>]"),
     (r"^mfma_i(\d)_areg64x64\+dense$", r"^k_conv_mfma_areg<\1, \d, \d, \d, (true|1)>"),
     (r"^mfma_i(\d)_areg64x64$", r"^k_conv_mfma_areg<\1, \d, \d, \d(, (false|0))?>"),
     (r"^mfma_i(\d)_wres256x64$", r"^k_conv_mfma_wres<\1,"),
