@@ -666,10 +666,22 @@ __device__ __forceinline__ void conv_mfma16_body(const MfmaGeom& mg, const EpiAr
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             float tv[4][4];                     // [b][r]
+            // float32 BN on value PAIRS: v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar forms and issue
+            // at the same rate (tools/micro/pk_f32_rate.hip), so the three operations cost 1.5 instructions per value instead
+            // of 3 -- the un-pooled int8 layers of VGG-large spend a fifth of their time in this epilogue (64 values per lane
+            // and tile, all 16 waves of the workgroup at once, nothing on the matrix pipe meanwhile)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < 4; ++b) {
+                const v2f nb2 = {fe[b].nb, fe[b].nb}, ninv2 = {fe[b].ninv, fe[b].ninv}, nshift2 = {fe[b].nshift, fe[b].nshift};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tv[b][r] = bn(acc[a][b][r], fe[b]);
+                for (int h = 0; h < 2; ++h) {
+                    v2f v = {(float)acc[a][b][2 * h], (float)acc[a][b][2 * h + 1]};
+                    v = v + nb2;
+                    v = v * ninv2;
+                    v = v + nshift2;
+                    tv[b][2 * h] = v[0]; tv[b][2 * h + 1] = v[1];
+                }
+            }
             if constexpr (OUT == QNN_STORE_F32) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
