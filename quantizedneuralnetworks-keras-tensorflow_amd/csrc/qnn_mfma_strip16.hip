@@ -145,9 +145,12 @@ __global__ __launch_bounds__(256, QNN_S16_BOUNDS) void k_conv_strip16_lds(MfmaGe
                 *reinterpret_cast<uint4*>(ss_lds + kSSlot + lane * 16) = s1;
             }
         }
-        v4i X[3];
-        X[0] = *reinterpret_cast<const v4i*>(xrd + 0 * kXRow);
-        X[1] = *reinterpret_cast<const v4i*>(xrd + 1 * kXRow);
+        // operand sets: input row k (relative to y0) lives in X[k & 3] and at ring position (k + 1) % 12
+        v4i X[4];
+        X[3] = *reinterpret_cast<const v4i*>(xrd + 0 * kXRow);
+        X[0] = *reinterpret_cast<const v4i*>(xrd + 1 * kXRow);
+        X[1] = *reinterpret_cast<const v4i*>(xrd + 2 * kXRow);
+        X[2] = *reinterpret_cast<const v4i*>(xrd + 3 * kXRow);
         uint32_t R[4] = {0, 0, 0, 0};                            // a four-row group's fields (bytes 1 and 3 of each)
 
         auto store_group = [&](bool all) {
@@ -166,32 +169,55 @@ __global__ __launch_bounds__(256, QNN_S16_BOUNDS) void k_conv_strip16_lds(MfmaGe
             orow += 4;
         };
 
+        // Software pipeline (QNN_S16_PIPE): an iteration issues the three MFMAs of row J + 1 BETWEEN the pieces of row J's
+        // epilogue.  A v_mfma_i32_16x16x64_i8 occupies the matrix pipe for 16 cycles but holds the SIMD's vector issue for 8
+        // (MI355X_MICROARCH.md, cycle constants): back to back the three dependent MFMAs of a row cost 48 cycles with nothing
+        // else issued, with four independent vector instructions behind each of them 3 x (8 + 16).  Left to itself the
+        // compiler hoists the MFMAs of several rows into clusters (with s_nop between dependent ones) and leaves the vector
+        // work as one long tail; the scheduling barriers below pin the interleaving (vector and matrix instructions may not
+        // cross them; memory instructions and scalar code may).
+        constexpr int kPin = 0x4 | 0x10 | 0x80;                  // sched_barrier mask: SALU, VMEM, DS may cross
+        v4i accp;                                                // accumulators of the row whose epilogue comes next
+        {
+            accp = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[0], X[3], binit, 0, 0, 0);
+            accp = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[1], X[0], accp, 0, 0, 0);
+            accp = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[2], X[1], accp, 0, 0, 0);
+        }
         auto body = [&](auto jc, bool full) {
-            constexpr int J = decltype(jc)::value;
-            constexpr int I = (J + 2) % 12;                      // ring position of the input row this body brings in
-            X[(J + 2) % 3] = *reinterpret_cast<const v4i*>(xrd + (I / 6) * kXSlot + (I % 6) * kXRow);
+            constexpr int J = decltype(jc)::value;               // epilogue of row J, MFMAs of row J + 1 (period 12)
+            // the operand of the row after next is requested now (input row J + 3 -> X[(J + 3) & 3]): a whole iteration
+            // of LDS latency before iteration J + 1 reads it
+            constexpr int I = (J + 4) % 12;
+            X[(J + 3) % 4] = *reinterpret_cast<const v4i*>(xrd + (I / 6) * kXSlot + (I % 6) * kXRow);
             uint32_t scf = 0;
             if constexpr (RES) {
                 scf = *reinterpret_cast<const unsigned short*>(srd + (J / 6) * kSSlot + (J % 6) * kSRow);
             }
-            v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[0], X[J % 3], binit, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[1], X[(J + 1) % 3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[2], X[(J + 2) % 3], acc, 0, 0, 0);
-            // folded epilogue (qnn_fold.h), pairs (c0, c2), (c1, c3)
-            uint32_t pe = qnn_fold_pair_m<FOLD>(acc[0], acc[2], fa[0], fa[2], fc[0], fc[2]);
-            uint32_t po = qnn_fold_pair_m<FOLD>(acc[1], acc[3], fa[1], fa[3], fc[1], fc[3]);
+            v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[0], X[J % 4], binit, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(kPin);
+            // folded epilogue of row J (qnn_fold.h), pairs (c0, c2), (c1, c3)
+            uint32_t pe = qnn_fold_pair_m<FOLD>(accp[0], accp[2], fa[0], fa[2], fc[0], fc[2]);
+            uint32_t y2 = 0;
             if constexpr (RES) {
                 const uint32_t w = scf ^ 0x8888u;
-                const uint32_t y2 = __builtin_amdgcn_perm(0u, w, 0x0C010C00u);
-                pe = qnn_fold_merge(pe, (y2 & 0x000F000Fu) << 10);
-                po = qnn_fold_merge(po, (y2 & 0x00F000F0u) << 6);
+                y2 = __builtin_amdgcn_perm(0u, w, 0x0C010C00u);
             }
+            __builtin_amdgcn_sched_barrier(kPin);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[1], X[(J + 1) % 4], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(kPin);
+            uint32_t po = qnn_fold_pair_m<FOLD>(accp[1], accp[3], fa[1], fa[3], fc[1], fc[3]);
+            if constexpr (RES) pe = qnn_fold_merge(pe, (y2 & 0x000F000Fu) << 10);
+            __builtin_amdgcn_sched_barrier(kPin);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(bw[2], X[(J + 2) % 4], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(kPin);
+            if constexpr (RES) po = qnn_fold_merge(po, (y2 & 0x00F000F0u) << 6);
             R[J % 4] = (po & 0xF000F000u) | ((pe >> 4) & ~0xF000F000u);       // bytes 1, 3 = (c1:c0), (c3:c2)
             if constexpr (J % 4 == 3) store_group(full);
-            if constexpr (J == 3) { xput(0); xload(); }          // slot 0's rows were last read by this row
+            if constexpr (J == 3) { xput(0); xload(); }          // slot 0's rows were last read one row ago
             if constexpr (J == 5) { sput(0); sload(); }
             if constexpr (J == 9) { xput(1); xload(); }
             if constexpr (J == 11) { sput(1); sload(); }
+            accp = acc;
         };
 #define B16(J, F) body(std::integral_constant<int, J>{}, F)
         int yy = y0;
